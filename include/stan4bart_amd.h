@@ -1,0 +1,188 @@
+/* stan4bart_amd.h — C-ABI of the MI355X-native stan4bart Gibbs hot path.
+ *
+ * This is the drop-in boundary for the reference's `.Call` layer (reference
+ * src/init.cpp:1215-1229 registration table).  Every entry point below names the reference
+ * routine it replaces.  The reference passes R SEXPs (S4 dbarts objects + named lists); here the
+ * same information travels as plain structs of scalars and pointers — no R, no torch types.
+ * An R shim (`INTEGRATION.md`) unpacks the SEXPs into these structs and forwards.
+ *
+ * Conventions
+ *   - all matrices are column-major (R layout); all pointers are host pointers unless the
+ *     struct says otherwise; inputs are copied at create time (reference copies X, y, CSR parts:
+ *     src/stan_sampler.cpp:35-65,197-249) except `offset`, which is copied too (the reference
+ *     borrows it, src/init.cpp:1033 — copying removes the lifetime hazard).
+ *   - every function returns 0 on success, non-zero on failure; `s4b_last_error()` returns the
+ *     message the R shim would hand to Rf_error (reference: Rf_error longjmp, src/init.cpp:319).
+ *   - one sampler == one chain == one GPU (reference: one chain per R worker process,
+ *     R/stan4bart_fit.R:527-533).  A sampler is not thread-safe; different samplers are independent.
+ *
+ * The symbol prefix is configurable so the CPU oracle (oracle/, test infrastructure only) can
+ * export the identical interface as `orc_*` for parity tests.
+ */
+#ifndef STAN4BART_AMD_H
+#define STAN4BART_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifndef S4B_PREFIX
+#define S4B_PREFIX s4b_
+#endif
+#define S4B_CAT_(a, b) a##b
+#define S4B_CAT(a, b) S4B_CAT_(a, b)
+#define S4B_FN(name) S4B_CAT(S4B_PREFIX, name)
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct s4b_sampler s4b_sampler; /* reference: `Sampler`, src/init.cpp:124-173, held in an externalptr */
+
+/* dbartsControl + dbartsModel fields the reference sets (R/stan4bart_fit.R:436-479) */
+typedef struct {
+  int32_t n_trees;      /* control@n.trees (bart_args$n.trees)                       */
+  int32_t n_thin;       /* control@n.thin = skip.bart (R/stan4bart_fit.R:438)         */
+  int32_t keep_trees;   /* control@keepTrees                                          */
+  int32_t node_capacity;/* 0 = default (256): max node slots per tree on the device   */
+  double base, power;   /* cgm(power = 2, base = 0.95)                                */
+  double k;             /* normal(k = 2)                                              */
+  double node_scale;    /* model@node.scale: 0.5 continuous, 3.0 binary (:477-479)    */
+  double birth_or_death_prob, swap_prob, change_prob, birth_prob; /* dbarts: .5 .1 .4 .5 */
+} s4b_bart_control;
+
+/* dbartsData slots (R/lme4_functions.R:176, R/stan4bart_fit.R:449-451) */
+typedef struct {
+  int64_t n;            /* numObservations                                            */
+  int32_t p;            /* numPredictors                                              */
+  int32_t reserved;
+  const double* x;      /* n x p, data@x                                              */
+  const int32_t* n_cuts;/* p, data@n.cuts (default 100 each)                          */
+  int64_t n_test;       /* numTestObservations                                        */
+  const double* x_test; /* n_test x p or NULL, data@x.test                            */
+} s4b_bart_data;
+
+/* the `stanData` list: same names as dataNames[] (reference src/stan_sampler.cpp:67-80) */
+typedef struct {
+  int64_t N; int32_t K;
+  int32_t is_binary, has_intercept, has_weights;
+  int32_t prior_dist, prior_dist_for_aux;           /* 0 none,1 normal,2 student_t / aux: +3 exponential */
+  const double* X;            /* N x K, column-centred fixed-effect design (R/rstanarm_functions.R:420-446) */
+  const double* y;            /* N */
+  const double* weights;      /* N or NULL */
+  const double* prior_scale;  /* K */
+  const double* prior_mean;   /* K */
+  const double* prior_df;     /* K */
+  double prior_scale_for_aux, prior_mean_for_aux, prior_df_for_aux;
+  int32_t t;                  /* number of grouping terms */
+  int32_t q;                  /* columns of Z */
+  int32_t len_theta_L, len_concentration, len_regularization, reserved;
+  const int32_t* p;           /* t */
+  const int32_t* l;           /* t */
+  const double* shape;        /* t */
+  const double* scale;        /* t */
+  const double* concentration;   /* len_concentration */
+  const double* regularization;  /* len_regularization */
+  int64_t num_non_zero;
+  const double* w;            /* num_non_zero: CSR values of Z  */
+  const int32_t* v;           /* num_non_zero: 0-based columns  */
+  const int32_t* u;           /* N + 1: 0-based row starts      */
+} s4b_stan_data;
+
+/* the `stanControl` list with the reference defaults (src/stan_sampler.cpp:395-458) */
+typedef struct {
+  uint32_t seed;              /* required */
+  int32_t skip;               /* <=0 : NA -> max(1,(2000 - warmup)/1000) (src/init.cpp:206-209) */
+  double init_r;              /* 2.0 */
+  double adapt_gamma, adapt_delta, adapt_kappa, adapt_t0;   /* .05 .8 .75 10 */
+  uint32_t adapt_init_buffer, adapt_term_buffer, adapt_window, reserved;  /* 75 50 25 */
+  double stepsize, stepsize_jitter;  /* 1, 0 */
+  int32_t max_treedepth;      /* 10 */
+  int32_t hmc_mode;           /* extension: 0 = sufficient-statistic (Gram) gradient, 1 = per-leapfrog O(N) kernels */
+} s4b_stan_control;
+
+typedef int (*s4b_callback_fn)(void* user, const double* yhat_train, const double* yhat_test,
+                               const double* stan_pars, int32_t num_pars);
+
+/* the `commonControl` list (src/init.cpp:199-202, 1015-1051) */
+typedef struct {
+  int32_t warmup, iter, verbose, refresh;
+  int32_t is_binary;
+  int32_t offset_type;        /* 0 default,1 fixef,2 ranef,3 bart,4 parametric (src/init.cpp:83-97) */
+  int32_t keep_fits;
+  int32_t device;             /* extension: HIP device ordinal for this chain */
+  const double* offset;       /* N or NULL: user offset */
+  const double* bart_offset_init; /* N or NULL */
+  double sigma_init;          /* > 0, default 1 */
+  s4b_callback_fn callback;   /* NULL or per-iteration callback (src/init.cpp:849-911) */
+  void* callback_user;
+} s4b_common_control;
+
+/* caller-allocated result buffers of one run() (layouts: src/stan_sampler.cpp:577-596, src/bart_util.cpp:13-81).
+ * num_samples = keep_fits ? num_iter : 1; any pointer may be NULL to skip that output. */
+typedef struct {
+  double* stan;          /* num_pars x num_samples */
+  double* bart_sigma;    /* num_samples            */
+  double* bart_train;    /* n x num_samples        */
+  double* bart_test;     /* n_test x num_samples   */
+  int32_t* bart_varcount;/* p x num_samples        */
+} s4b_results;
+
+/* R's generator state as 625 words {mti, mt[0..623]} == .Random.seed[2:626]
+ * (reference brackets every entry with GetRNGstate/PutRNGstate: src/init.cpp:259,298,750,919) */
+#define S4B_R_RNG_WORDS 625
+
+const char* S4B_FN(last_error)(void);
+
+/* stan4bart_create(bartControl, bartData, bartModel, stanData, stanControl, commonControl) — src/init.cpp:190-310 */
+int S4B_FN(create)(const s4b_bart_control* bart_control, const s4b_bart_data* bart_data,
+                   const s4b_stan_data* stan_data, const s4b_stan_control* stan_control,
+                   const s4b_common_control* common_control, const uint32_t* r_rng_state,
+                   s4b_sampler** out);
+
+/* stan4bart_run(sampler, numIter, isWarmup, resultsType) — src/init.cpp:678-965; results_type 0 both,1 bart,2 stan */
+int S4B_FN(run)(s4b_sampler* s, int32_t num_iter, int32_t is_warmup, int32_t results_type, s4b_results* out);
+
+/* stan4bart_disengageAdaptation — src/init.cpp:995-1004 */
+int S4B_FN(disengage_adaptation)(s4b_sampler* s);
+
+/* stan4bart_printInitialSummary — src/init.cpp:971-993 (writes to stdout) */
+int S4B_FN(print_initial_summary)(s4b_sampler* s);
+
+/* stan4bart_getParametricMean — src/init.cpp:332-347: X beta + Z b of the last Stan draw, N doubles */
+int S4B_FN(get_parametric_mean)(s4b_sampler* s, double* out);
+
+/* stan4bart_getBARTDataRange — src/init.cpp:316-330: {min, max} of the response rescaling */
+int S4B_FN(get_bart_data_range)(s4b_sampler* s, double out[2]);
+
+/* PutRNGstate()/GetRNGstate() counterparts */
+int S4B_FN(get_r_rng_state)(s4b_sampler* s, uint32_t* state);
+int S4B_FN(set_r_rng_state)(s4b_sampler* s, const uint32_t* state);
+
+/* sizes: num_pars (rows of the stan result), n, n_test, p, n_trees */
+int S4B_FN(get_dims)(s4b_sampler* s, int64_t dims[5]);
+
+/* row names of the stan result (src/stan_sampler.cpp:476-489): writes a '\n'-joined list */
+int S4B_FN(get_stan_par_names)(s4b_sampler* s, char* buf, size_t cap);
+
+/* stan4bart_getTrees(current = TRUE) — src/init.cpp:514-671 flattened-tree layout for the live trees:
+ * preorder per tree; var >= 0: internal node (value = cut point), var = -1: leaf (value = mu on the
+ * rescaled scale).  Returns the node count through *num_nodes; arrays may be NULL to query the size. */
+int S4B_FN(get_trees)(s4b_sampler* s, int64_t cap, int32_t* tree, int32_t* n_obs, int32_t* var,
+                      int32_t* split, double* value, int64_t* num_nodes);
+
+/* diagnostics used by the parity tests: per-tree-update trace records of 5 int32
+ * {type 0 birth 1 death 2 swap 3 change, status 1/0/-1, var, split, num_leaves} */
+int S4B_FN(set_trace)(s4b_sampler* s, int32_t enable);
+int S4B_FN(get_trace)(s4b_sampler* s, int64_t cap_records, int32_t* out, int64_t* num_records);
+/* DFS leaf rank of every training observation in tree t (n int32) */
+int S4B_FN(get_leaf_assignment)(s4b_sampler* s, int32_t tree, int32_t* out);
+/* counters: {log-density gradient evaluations, tree updates, device kernel launches} */
+int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
+
+/* finalizer of the externalptr — src/init.cpp:1152-1165 */
+void S4B_FN(free)(s4b_sampler* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STAN4BART_AMD_H */

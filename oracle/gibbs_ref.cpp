@@ -1,0 +1,310 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+//
+// CPU restatement of the reference's blocked Gibbs driver:
+//   createSampler   reference src/init.cpp:190-310   (init order: Stan init + init_stepsize against
+//                   offset_ = 0, then setOffset(updateScale) / setSigma / trees from prior / one
+//                   un-recorded BART sweep / first stanOffset)
+//   run             reference src/init.cpp:678-965   (loop body :752-917)
+//   disengage       reference src/init.cpp:995-1004
+// exported with the same C interface as the product (include/stan4bart_amd.h) under the
+// `orc_` prefix, so tests drive both through one wrapper.  Single-threaded, as the reference
+// (R/stan4bart_fit.R:437-439).
+#define S4B_PREFIX orc_
+#include "../include/stan4bart_amd.h"
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+#include "bart_ref.hpp"
+#include "stan_ref.hpp"
+
+using namespace oracle;
+
+namespace {
+thread_local std::string g_err;
+
+enum { OFFSET_DEFAULT = 0, OFFSET_FIXEF, OFFSET_RANEF, OFFSET_BART, OFFSET_PARAMETRIC };
+}  // namespace
+
+struct s4b_sampler {
+  int warmup = 0, iter = 0, verbose = 0, refresh = 0;
+  bool binary = false, keepFits = true;
+  int offsetType = 0;
+  std::vector<double> userOffset; bool hasUserOffset = false;
+  s4b_callback_fn callback = nullptr; void* callbackUser = nullptr;
+  RRng rrng;
+  std::unique_ptr<StanModel> model;
+  std::unique_ptr<NutsSampler> nuts;
+  std::unique_ptr<BartFit> bart;
+  std::vector<double> bartOffset, stanOffset, bartLatents;
+  std::vector<double> row;   // last written Stan sample row (x_curr)
+  size_t n = 0;
+  long treeUpdates = 0;
+};
+
+static StanData convert(const s4b_stan_data& d) {
+  StanData s;
+  s.N = d.N; s.K = d.K;
+  s.X.assign(d.X, d.X + (size_t)d.N * d.K);
+  s.y.assign(d.y, d.y + d.N);
+  s.is_binary = d.is_binary; s.has_intercept = d.has_intercept;
+  s.prior_dist = d.prior_dist; s.prior_dist_for_aux = d.prior_dist_for_aux;
+  if (d.K) { s.prior_scale.assign(d.prior_scale, d.prior_scale + d.K); s.prior_mean.assign(d.prior_mean, d.prior_mean + d.K);
+             s.prior_df.assign(d.prior_df, d.prior_df + d.K); }
+  s.prior_scale_for_aux = d.prior_scale_for_aux; s.prior_mean_for_aux = d.prior_mean_for_aux; s.prior_df_for_aux = d.prior_df_for_aux;
+  s.t = d.t; s.q = d.q; s.len_theta_L = d.len_theta_L;
+  if (d.t) { s.p.assign(d.p, d.p + d.t); s.l.assign(d.l, d.l + d.t); s.shape.assign(d.shape, d.shape + d.t); s.scale.assign(d.scale, d.scale + d.t); }
+  if (d.len_concentration) s.concentration.assign(d.concentration, d.concentration + d.len_concentration);
+  if (d.len_regularization) s.regularization.assign(d.regularization, d.regularization + d.len_regularization);
+  if (d.num_non_zero) { s.w.assign(d.w, d.w + d.num_non_zero); s.v.assign(d.v, d.v + d.num_non_zero); }
+  s.u.assign(d.N + 1, 0);
+  if (d.u) s.u.assign(d.u, d.u + d.N + 1);
+  s.has_weights = d.has_weights;
+  if (d.has_weights) s.weights.assign(d.weights, d.weights + d.N);
+  s.offset_.assign(d.N, 0.0);
+  return s;
+}
+
+extern "C" {
+
+const char* orc_last_error(void) { return g_err.c_str(); }
+
+int orc_create(const s4b_bart_control* bc, const s4b_bart_data* bd, const s4b_stan_data* sd,
+               const s4b_stan_control* sc, const s4b_common_control* cc, const uint32_t* r_rng_state,
+               s4b_sampler** out) {
+  try {
+    std::unique_ptr<s4b_sampler> sp(new s4b_sampler);
+    s4b_sampler& s = *sp;
+    s.warmup = cc->warmup; s.iter = cc->iter; s.verbose = cc->verbose; s.refresh = cc->refresh;
+    s.binary = cc->is_binary != 0; s.keepFits = cc->keep_fits != 0; s.offsetType = cc->offset_type;
+    s.callback = cc->callback; s.callbackUser = cc->callback_user;
+    s.n = (size_t)bd->n;
+    if (bd->n != sd->N) throw std::invalid_argument("bart data n != stan data N");
+    if (!(cc->sigma_init > 0)) throw std::invalid_argument("sigma_init must be > 0");
+    if (cc->offset) { s.userOffset.assign(cc->offset, cc->offset + s.n); s.hasUserOffset = true; }
+    s.rrng.mti = (int)r_rng_state[0];
+    std::memcpy(s.rrng.mt, r_rng_state + 1, 624 * sizeof(uint32_t));
+
+    s.model.reset(new StanModel(convert(*sd)));
+    StanControl ctl;
+    ctl.seed = sc->seed; ctl.init_radius = sc->init_r; ctl.skip = sc->skip;
+    if (ctl.skip <= 0) { ctl.skip = (2000 - s.warmup) / 1000; if (ctl.skip < 1) ctl.skip = 1; }
+    ctl.adapt_gamma = sc->adapt_gamma; ctl.adapt_delta = sc->adapt_delta; ctl.adapt_kappa = sc->adapt_kappa; ctl.adapt_t0 = sc->adapt_t0;
+    ctl.init_buffer = sc->adapt_init_buffer; ctl.term_buffer = sc->adapt_term_buffer; ctl.window = sc->adapt_window;
+    ctl.stepsize = sc->stepsize; ctl.stepsize_jitter = sc->stepsize_jitter; ctl.max_treedepth = sc->max_treedepth;
+    s.nuts.reset(new NutsSampler(*s.model, ctl, 1, s.warmup));
+    s.row.assign((size_t)s.model->n_row, 0.0);
+
+    BartConfig cfg;
+    cfg.numTrees = bc->n_trees; cfg.thin = bc->n_thin > 0 ? bc->n_thin : 1; cfg.binary = s.binary;
+    cfg.base = bc->base; cfg.power = bc->power; cfg.k = bc->k; cfg.nodeScale = bc->node_scale;
+    cfg.birthOrDeathProb = bc->birth_or_death_prob; cfg.swapProb = bc->swap_prob; cfg.changeProb = bc->change_prob; cfg.birthProb = bc->birth_prob;
+    std::vector<int> ncuts(bd->n_cuts, bd->n_cuts + bd->p);
+    s.bart.reset(new BartFit(cfg, s.n, (size_t)bd->p, bd->x, sd->y, ncuts.data(), (size_t)bd->n_test, bd->x_test, &s.rrng));
+
+    s.bartOffset.assign(s.n, 0.0); s.stanOffset.assign(s.n, 0.0);
+    if (s.binary) s.bartLatents.assign(s.n, 0.0);
+    const double* boi = cc->bart_offset_init;
+    if (s.hasUserOffset) {
+      if (s.offsetType != OFFSET_BART) {
+        s.bartOffset = s.userOffset;
+        if (boi && s.offsetType == OFFSET_DEFAULT) for (size_t i = 0; i < s.n; ++i) s.bartOffset[i] += boi[i];
+      } else if (boi) s.bartOffset.assign(boi, boi + s.n);
+    } else if (boi) s.bartOffset.assign(boi, boi + s.n);
+
+    s.bart->setOffset(s.bartOffset.data(), true);
+    if (!s.binary) s.bart->setSigma(cc->sigma_init);
+    s.bart->sampleTreesFromPrior();
+    BartResults first;
+    s.bart->runSampler(first);
+    for (size_t j = 0; j < s.n; ++j) first.train[j] -= s.bartOffset[j];
+    if (s.hasUserOffset && s.offsetType == OFFSET_BART) s.stanOffset = s.userOffset;
+    else {
+      s.stanOffset = first.train;
+      if (s.hasUserOffset && s.offsetType == OFFSET_DEFAULT) for (size_t j = 0; j < s.n; ++j) s.stanOffset[j] += s.userOffset[j];
+    }
+    s.model->set_offset(s.stanOffset.data());
+    if (s.binary) { s.bart->getLatents(s.bartLatents.data()); s.model->set_response(s.bartLatents.data()); }
+    *out = sp.release();
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+int orc_run(s4b_sampler* sp, int32_t numIter, int32_t isWarmup, int32_t resultsType, s4b_results* out) {
+  try {
+    if (!sp) throw std::invalid_argument("run called on NULL sampler");
+    if (numIter < 1) throw std::invalid_argument("num_iter must be >= 1");
+    s4b_sampler& s = *sp;
+    const size_t n = s.n, nTest = s.bart->nTest, p = s.bart->p;
+    const int numPars = s.model->n_row;
+    const bool doStan = resultsType == 0 || resultsType == 2, doBart = resultsType == 0 || resultsType == 1;
+    size_t slot = 0;
+    BartResults res;
+    for (int iter = 0; iter < numIter; ++iter) {
+      if (doStan) {
+        s.nuts->run(s.row.data());
+        const double* cons = s.row.data() + 7;
+        if (!s.hasUserOffset) s.model->parametric_mean(cons, s.bartOffset.data(), true, true);
+        else switch (s.offsetType) {
+          case OFFSET_DEFAULT:
+            s.model->parametric_mean(cons, s.bartOffset.data(), true, true);
+            for (size_t j = 0; j < n; ++j) s.bartOffset[j] += s.userOffset[j];
+            break;
+          case OFFSET_BART: s.model->parametric_mean(cons, s.bartOffset.data(), true, true); break;
+          case OFFSET_RANEF:
+            s.model->parametric_mean(cons, s.bartOffset.data(), true, false);
+            for (size_t j = 0; j < n; ++j) s.bartOffset[j] += s.userOffset[j];
+            break;
+          case OFFSET_FIXEF:
+            s.model->parametric_mean(cons, s.bartOffset.data(), false, true);
+            for (size_t j = 0; j < n; ++j) s.bartOffset[j] += s.userOffset[j];
+            break;
+          case OFFSET_PARAMETRIC: s.bartOffset = s.userOffset; break;
+        }
+        if (!s.binary) s.bart->setSigma(cons[s.model->aux_pos()]);
+        if (out && out->stan) std::memcpy(out->stan + slot * numPars, s.row.data(), numPars * sizeof(double));
+        int update_scale_mod = 1 << (8 * iter / numIter);
+        s.bart->setOffset(s.bartOffset.data(), isWarmup && iter % update_scale_mod == 0);
+      }
+      if (doBart) {
+        s.bart->runSampler(res);
+        s.treeUpdates += (long)s.bart->cfg.numTrees * s.bart->cfg.thin;
+        for (size_t j = 0; j < n; ++j) res.train[j] -= s.bartOffset[j];
+        if (s.hasUserOffset && s.offsetType == OFFSET_BART) s.stanOffset = s.userOffset;
+        else {
+          s.stanOffset = res.train;
+          if (s.hasUserOffset && s.offsetType == OFFSET_DEFAULT) for (size_t j = 0; j < n; ++j) s.stanOffset[j] += s.userOffset[j];
+        }
+        s.model->set_offset(s.stanOffset.data());
+        if (s.binary) { s.bart->getLatents(s.bartLatents.data()); s.model->set_response(s.bartLatents.data()); }
+        if (out) {
+          if (out->bart_sigma) out->bart_sigma[slot] = res.sigma;
+          if (out->bart_train) std::memcpy(out->bart_train + slot * n, res.train.data(), n * sizeof(double));
+          if (out->bart_test && nTest) std::memcpy(out->bart_test + slot * nTest, res.test.data(), nTest * sizeof(double));
+          if (out->bart_varcount) for (size_t j = 0; j < p; ++j) out->bart_varcount[slot * p + j] = (int32_t)res.varcount[j];
+        }
+        if (s.callback) s.callback(s.callbackUser, res.train.data(), nTest ? res.test.data() : nullptr, s.row.data(), numPars);
+      }
+      if (s.keepFits) ++slot;
+    }
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+int orc_disengage_adaptation(s4b_sampler* s) {
+  if (!s) { g_err = "disengageAdaptation called on NULL sampler"; return 1; }
+  s->nuts->disengage_adaptation();
+  return 0;
+}
+
+int orc_print_initial_summary(s4b_sampler* s) {
+  if (!s) { g_err = "printInitialSummary called on NULL sampler"; return 1; }
+  std::printf("stan4bart oracle: n = %zu, p = %zu, trees = %d, stan params = %d\n", s->n, s->bart->p, s->bart->cfg.numTrees, s->model->D);
+  return 0;
+}
+
+int orc_get_parametric_mean(s4b_sampler* s, double* out) {
+  if (!s) { g_err = "getParametricMean called on NULL sampler"; return 1; }
+  s->model->parametric_mean(s->row.data() + 7, out, true, true);
+  return 0;
+}
+
+int orc_get_bart_data_range(s4b_sampler* s, double out[2]) {
+  if (!s) { g_err = "getBARTDataRange called on NULL sampler"; return 1; }
+  out[0] = s->bart->scaleMin; out[1] = s->bart->scaleMax;
+  return 0;
+}
+
+int orc_get_r_rng_state(s4b_sampler* s, uint32_t* st) { st[0] = (uint32_t)s->rrng.mti; std::memcpy(st + 1, s->rrng.mt, 624 * 4); return 0; }
+int orc_set_r_rng_state(s4b_sampler* s, const uint32_t* st) { s->rrng.mti = (int)st[0]; std::memcpy(s->rrng.mt, st + 1, 624 * 4); return 0; }
+
+int orc_get_dims(s4b_sampler* s, int64_t d[5]) {
+  d[0] = s->model->n_row; d[1] = (int64_t)s->n; d[2] = (int64_t)s->bart->nTest; d[3] = (int64_t)s->bart->p; d[4] = s->bart->cfg.numTrees;
+  return 0;
+}
+
+int orc_get_stan_par_names(s4b_sampler* s, char* buf, size_t cap) {
+  const StanModel& m = *s->model;
+  std::string o = "lp__\naccept_stat__\nstepsize__\ntreedepth__\nn_leapfrog__\ndivergent__\nenergy__";
+  auto add = [&](const char* base, int cnt) { for (int i = 1; i <= cnt; ++i) o += "\n" + std::string(base) + "." + std::to_string(i); };
+  add("z_beta", m.dat.K); add("z_b", m.dat.q); add("z_T", m.len_z_T); add("rho", m.len_rho); add("zeta", m.len_conc); add("tau", m.dat.t);
+  if (!m.dat.is_binary) { add("aux_unscaled", 1); add("aux", 1); }
+  add("beta", m.dat.K); add("b", m.dat.q); add("theta_L", m.dat.len_theta_L);
+  if (o.size() + 1 > cap) { g_err = "name buffer too small"; return 1; }
+  std::memcpy(buf, o.c_str(), o.size() + 1);
+  return 0;
+}
+
+int orc_get_trees(s4b_sampler* s, int64_t cap, int32_t* tree, int32_t* n_obs, int32_t* var, int32_t* split, double* value, int64_t* num_nodes) {
+  int64_t cnt = 0;
+  for (int t = 0; t < s->bart->cfg.numTrees; ++t) {
+    std::vector<int32_t> st; std::vector<double> mu;
+    s->bart->serializeTree(t, st, mu);
+    // n_obs of an internal node = sum of its leaves' counts (preorder recursion)
+    size_t nn = st.size() / 2; std::vector<int32_t> cntObs(nn, 0);
+    {
+      size_t cursor = 0;
+      struct Rec { static int32_t go(const std::vector<int32_t>& st, std::vector<int32_t>& c, size_t& k) {
+        size_t me = k++;
+        if (st[2 * me] < 0) { c[me] = st[2 * me + 1]; return c[me]; }
+        int32_t a = go(st, c, k); int32_t b = go(st, c, k); c[me] = a + b; return c[me]; } };
+      Rec::go(st, cntObs, cursor);
+    }
+    size_t leaf = 0;
+    for (size_t k = 0; k < nn; ++k, ++cnt) {
+      if (cnt < cap && tree) {
+        tree[cnt] = t; n_obs[cnt] = cntObs[k]; var[cnt] = st[2 * k];
+        if (st[2 * k] >= 0) { split[cnt] = st[2 * k + 1]; value[cnt] = s->bart->cuts[(size_t)st[2 * k]][(size_t)st[2 * k + 1]]; }
+        else { split[cnt] = -1; value[cnt] = mu[leaf]; }
+      }
+      if (st[2 * k] < 0) ++leaf;
+    }
+  }
+  *num_nodes = cnt;
+  return 0;
+}
+
+int orc_set_trace(s4b_sampler* s, int32_t enable) { s->bart->keepTrace = enable != 0; s->bart->trace.clear(); return 0; }
+int orc_get_trace(s4b_sampler* s, int64_t cap, int32_t* out, int64_t* num) {
+  int64_t m = (int64_t)s->bart->trace.size();
+  *num = m;
+  for (int64_t i = 0; i < m && i < cap; ++i) std::memcpy(out + 5 * i, &s->bart->trace[(size_t)i], 5 * sizeof(int32_t));
+  s->bart->trace.clear();
+  return 0;
+}
+int orc_get_leaf_assignment(s4b_sampler* s, int32_t t, int32_t* out) {
+  std::vector<int32_t> a; s->bart->leafAssignment(t, a); std::memcpy(out, a.data(), a.size() * sizeof(int32_t)); return 0;
+}
+int orc_get_counters(s4b_sampler* s, int64_t out[3]) { out[0] = s->model->gradEvals; out[1] = s->treeUpdates; out[2] = 0; return 0; }
+
+void orc_free(s4b_sampler* s) { delete s; }
+
+// ---- small extras used only by tests: direct access to the RNG restatements and the model ----
+void orc_test_r_rng(uint32_t seed, int32_t n_unif, double* unif, int32_t n_norm, double* norm, int32_t n_exp, double* ex,
+                    int32_t n_idx, double dn, double* idx) {
+  RRng r; r.set_seed(seed);
+  for (int i = 0; i < n_unif; ++i) unif[i] = r.unif_rand();
+  for (int i = 0; i < n_norm; ++i) norm[i] = r.norm_rand();
+  for (int i = 0; i < n_exp; ++i) ex[i] = r.exp_rand();
+  for (int i = 0; i < n_idx; ++i) idx[i] = r.unif_index(dn);
+}
+void orc_test_r_seed_state(uint32_t seed, uint32_t* state) { RRng r; r.set_seed(seed); state[0] = (uint32_t)r.mti; std::memcpy(state + 1, r.mt, 624 * 4); }
+double orc_test_qnorm(double p) { return RRng::qnorm(p); }
+uint32_t orc_test_ecuyer_nth(uint32_t nth) { Ecuyer1988 e; e.x1 = 1; e.x2 = 1; uint32_t v = 0; for (uint32_t i = 0; i < nth; ++i) v = e.next(); return v; }
+void orc_test_boost_draws(uint32_t seed, uint32_t chain, int32_t n_u, double* u, int32_t n_norm, double* norm) {
+  Ecuyer1988 e; e.create(seed, chain);
+  for (int i = 0; i < n_u; ++i) u[i] = e.uniform01();
+  for (int i = 0; i < n_norm; ++i) norm[i] = boost_normal(e);
+}
+// log density + gradient of the Stan model at an arbitrary unconstrained point
+int orc_test_log_prob_grad(s4b_sampler* s, const double* q, double* lp, double* grad) {
+  std::vector<double> qv(q, q + s->model->D), g;
+  *lp = s->model->log_prob_grad(qv, g);
+  std::memcpy(grad, g.data(), g.size() * sizeof(double));
+  return 0;
+}
+int orc_test_num_unconstrained(s4b_sampler* s) { return s->model->D; }
+
+}  // extern "C"

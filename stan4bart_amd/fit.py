@@ -1,0 +1,208 @@
+"""Host-side mirror of the reference's R fit driver for the hot path.
+
+Follows reference R/stan4bart_fit.R: the six argument objects handed to ``stan4bart_create``
+(`:259-365` data.stan, `:482-488` control.stan, `:490-493` control.common, `:436-479` dbarts
+control/model), the per-chain worker (`:33-60`) and the chain fan-out (`:495-558`).  There is no R
+in this image, so the model-frame plumbing of R/stan4bart.R / R/lme4_functions.R is replaced by
+explicit arrays: ``y``, the BART predictor matrix, the fixed-effect design and a list of grouping
+terms.  Everything numeric that reaches the C boundary is computed as the R code computes it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from .abi import Sampler, SamplerArgs
+from .rcompat import RRng
+
+INT_MAX = 2147483647
+
+
+@dataclass
+class GroupTerm:
+    """One ``(1 + slopes | g)`` term: ``levels`` are 1-based integer codes, ``slopes`` n x (p-1)."""
+    levels: np.ndarray
+    slopes: Optional[np.ndarray] = None
+    name: str = "g"
+
+    @property
+    def p(self) -> int:
+        return 1 + (0 if self.slopes is None else np.atleast_2d(self.slopes.T).shape[0])
+
+    @property
+    def l(self) -> int:
+        return int(np.max(self.levels))
+
+
+def center_x(X: np.ndarray):
+    """reference R/rstanarm_functions.R:420-446 (no intercept column: BART supplies it)."""
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim == 1:
+        X = X.reshape(-1, 1)
+    xbar = X.mean(axis=0) if X.shape[1] else np.zeros(0)
+    return X - xbar, xbar
+
+
+def make_z_csr(groups: Sequence[GroupTerm], n: int):
+    """CSR parts (w, v, u) of Z = t(Zt) (reference R/stan4bart_fit.R:290,313-317; column order =
+    lme4 Zt row order: terms by decreasing number of levels, level-major within a term)."""
+    order = sorted(range(len(groups)), key=lambda i: -groups[i].l)
+    terms = [groups[i] for i in order]
+    p = [g.p for g in terms]
+    l = [g.l for g in terms]
+    z = int(sum(p))
+    w = np.zeros((n, z))
+    v = np.zeros((n, z), dtype=np.int32)
+    base, col = 0, 0
+    for g, pi, li in zip(terms, p, l):
+        lev = np.asarray(g.levels, dtype=np.int64) - 1
+        vals = np.ones((n, pi))
+        if pi > 1:
+            vals[:, 1:] = np.asarray(g.slopes, dtype=np.float64).reshape(n, pi - 1)
+        for c in range(pi):
+            w[:, col + c] = vals[:, c]
+            v[:, col + c] = base + lev * pi + c
+        base += pi * li
+        col += pi
+    u = (np.arange(n + 1, dtype=np.int64) * z).astype(np.int32)
+    return terms, p, l, w.reshape(-1), v.reshape(-1), u, base
+
+
+def init_fit(y, Xc, groups, n, is_binary):
+    """bart_offset_init / sigma_init from the lm fallback of reference R/stan4bart.R:160-186
+    (``subbars``: grouping factors enter as fixed dummies).  lme4 is not available here."""
+    cols = [np.ones(n)]
+    if Xc.shape[1]:
+        cols += [Xc[:, j] for j in range(Xc.shape[1])]
+    for g in groups:
+        lev = np.asarray(g.levels, dtype=np.int64)
+        for k in range(2, g.l + 1):
+            cols.append((lev == k).astype(float))
+    A = np.stack(cols, axis=1)
+    if is_binary:
+        return None, 1.0
+    coef, *_ = np.linalg.lstsq(A, y, rcond=None)
+    fitted = A @ coef
+    rank = np.linalg.matrix_rank(A)
+    sigma = float(np.sqrt(np.sum((y - fitted) ** 2) / max(1, n - rank)))
+    return fitted, sigma
+
+
+def make_sampler_args(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_test=None, family: str = "gaussian",
+                      iter: int = 2000, warmup: int = 1000, skip=1, keep_fits: bool = True, callback=None,
+                      offset=None, offset_type: str = "default", weights=None,
+                      stan_args: Optional[dict] = None, bart_args: Optional[dict] = None, verbose: int = 0,
+                      refresh: Optional[int] = None, device: int = 0) -> SamplerArgs:
+    stan_args = dict(stan_args or {})
+    bart_args = dict(bart_args or {})
+    y = np.asarray(y, dtype=np.float64)
+    n = len(y)
+    is_binary = family == "binomial"
+    Xc, xbar = center_x(X if X is not None else np.zeros((n, 0)))
+    K = Xc.shape[1]
+
+    # priors (reference R/stan4bart_fit.R:100-232): normal(0, 2.5, autoscale), exponential(1, autoscale)
+    prior_scale = np.full(K, float(stan_args.get("prior_scale", 2.5)))
+    ss = float(np.std(y, ddof=1)) if not is_binary else 1.0
+    if not is_binary:
+        prior_scale = ss * prior_scale
+    for k in range(K):
+        xs = 1.0 if len(np.unique(Xc[:, k])) == 1 else float(np.std(Xc[:, k], ddof=1))
+        prior_scale[k] = max(1e-12, prior_scale[k] / xs)
+    prior_scale_for_aux = 0.0 if is_binary else ss * 1.0
+
+    terms, p, l, w, v, u, q = make_z_csr(groups, n) if len(groups) else ([], [], [], np.zeros(0), np.zeros(0, np.int32),
+                                                                        np.zeros(n + 1, np.int32), 0)
+    t = len(p)
+    decov = stan_args.get("prior_covariance", dict(regularization=1.0, concentration=1.0, shape=1.0, scale=1.0))
+    n_conc = int(sum(pi for pi in p if pi > 1))
+    n_reg = int(sum(1 for pi in p if pi > 1))
+
+    boi, sigma_init = init_fit(y, Xc, list(groups), n, is_binary)
+    if isinstance(skip, (tuple, list)):
+        skip_bart, skip_stan = int(skip[0]), int(skip[1] if len(skip) > 1 else skip[0])
+    else:
+        skip_bart = skip_stan = int(skip)
+    if refresh is None:
+        refresh = max(iter // 10, 1)
+    off_types = ["default", "fixef", "ranef", "bart", "parametric"]
+    return SamplerArgs(
+        x_bart=np.asarray(x_bart, dtype=np.float64), x_test=x_test,
+        n_trees=int(bart_args.get("n.trees", 75)), n_cuts=bart_args.get("n.cuts", 100), n_thin=skip_bart,
+        base=float(bart_args.get("base", 0.95)), power=float(bart_args.get("power", 2.0)),
+        k=float(bart_args.get("k", 2.0)), keep_trees=bool(bart_args.get("keepTrees", False)),
+        node_scale=3.0 if is_binary else 0.5,
+        X=Xc, y=y, weights=weights, is_binary=is_binary, prior_dist=1, prior_dist_for_aux=0 if is_binary else 3,
+        prior_scale=prior_scale, prior_mean=np.zeros(K), prior_df=np.ones(K),
+        prior_scale_for_aux=prior_scale_for_aux, prior_mean_for_aux=0.0, prior_df_for_aux=1.0,
+        p=p, l=l, shape=[float(decov["shape"])] * t, scale=[float(decov["scale"])] * t,
+        concentration=[float(decov["concentration"])] * n_conc, regularization=[float(decov["regularization"])] * n_reg,
+        w=w, v=v, u=u,
+        skip=skip_stan, init_r=float(stan_args.get("init_r", 2.0)),
+        adapt_gamma=float(stan_args.get("adapt_gamma", 0.05)), adapt_delta=float(stan_args.get("adapt_delta", 0.8)),
+        adapt_kappa=float(stan_args.get("adapt_kappa", 0.75)), hmc_mode=int(stan_args.get("hmc_mode", 0)),
+        warmup=warmup, iter=iter, verbose=verbose, refresh=refresh,
+        offset=offset, offset_type=off_types.index(offset_type),
+        bart_offset_init=boi, sigma_init=sigma_init, keep_fits=keep_fits, callback=callback, device=device,
+        extras=dict(xbar=xbar, group_terms=terms),
+    )
+
+
+def fit_worker(make_sampler: Callable[[SamplerArgs, np.ndarray], Sampler], args: SamplerArgs, rng: RRng) -> dict:
+    """reference stan4bart_fit_worker (R/stan4bart_fit.R:33-60): seed Stan from R's stream, create,
+    warmup, disengage adaptation, sample.  ``rng`` is advanced in place (PutRNGstate semantics)."""
+    args.seed = int(rng.sample_int(INT_MAX, 1)[0])
+    sampler = make_sampler(args, rng.state)
+    results: dict = {}
+    try:
+        if args.verbose > 0:
+            sampler.print_initial_summary()
+        if args.warmup > 0:
+            results["warmup"] = sampler.run(args.warmup, True, 0)
+        sampler.disengage_adaptation()
+        results["sample"] = sampler.run(args.iter - args.warmup, False, 0)
+        results["par_names"] = sampler.stan_par_names()
+        results["range.bart"] = sampler.get_bart_data_range()
+        if args.keep_trees:
+            results["trees"] = sampler.get_trees()
+        rng.state = sampler.get_r_rng_state()
+    finally:
+        sampler.free()
+    return results
+
+
+def hip_sampler_factory():
+    from ._lib import load_library
+    lib = load_library()
+    return lambda a, st: Sampler(lib, "s4b_", a, st)
+
+
+def stan4bart_fit(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), chains: int = 4, seed: Optional[int] = None,
+                  make_sampler: Optional[Callable] = None, **kw) -> list:
+    """Serial multi-chain fit with the reference's single-threaded seeding rule
+    (R/stan4bart_fit.R:545-554: ``set.seed(seed)`` once, chains continue one stream)."""
+    make_sampler = make_sampler or hip_sampler_factory()
+    rng = RRng(seed if seed is not None else int.from_bytes(os.urandom(4), "little"))
+    out = []
+    for c in range(chains):
+        args = make_sampler_args(y, x_bart, X=X, groups=groups, **kw)
+        out.append(fit_worker(make_sampler, args, rng))
+    return out
+
+
+def chain_seeds(seed: int, chains: int) -> np.ndarray:
+    """Per-worker seeds of the parallel path (R/stan4bart_fit.R:515-516):
+    ``set.seed(seed); sample.int(.Machine$integer.max, chains)``."""
+    return RRng(seed).sample_int(INT_MAX, chains)
+
+
+def fit_chain_parallel(chain: int, seed: int, chains: int, make_sampler: Callable, y, x_bart, **kw) -> dict:
+    """One chain of the parallel path: worker ``chain`` does ``set.seed(randomSeeds[chain])`` first
+    (R/stan4bart_fit.R:35-36,527-533).  Called by one process per GPU."""
+    rng = RRng(int(chain_seeds(seed, chains)[chain]))
+    args = make_sampler_args(y, x_bart, **kw)
+    return fit_worker(make_sampler, args, rng)
