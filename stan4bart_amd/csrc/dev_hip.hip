@@ -1,0 +1,823 @@
+// HIP device layer of the stan4bart Gibbs hot path for MI355X (gfx950, wave64).
+//
+// Replaces, on the device, the O(N) work the reference does on one CPU thread per chain:
+//   * dbarts' per-tree passes behind bartFunctions.runSamplerWithResults (reference src/init.cpp:824):
+//     partial residual, per-leaf sufficient statistics, proposal statistics, leaf-value scatter
+//       -> k_stats / k_control / k_apply          (algorithmic bytes 22 N per tree)
+//   * dbarts setOffset / setSigma (reference src/init.cpp:799,817) -> k_param_mean / k_scale / k_rescale
+//   * the residual hand-off (reference src/stan_files/continuous.hpp:3631-3768, src/init.cpp:828-842)
+//     and the O(N) sums of the Stan log density (continuous.hpp:2438-2470)
+//       -> k_stan_inputs / k_zt_chunks / k_leapfrog  (§8 a7, a11, a12)
+// Design rules: all per-observation arrays are structure-of-arrays and read/written as
+// 8–32 B per lane; the binned predictors are u16 with one column contiguous; every reduction has a
+// fixed grid and a fixed combination order, so a chain is reproducible run to run; accept/reject and
+// the R-compatible random stream stay on the device (one lane of k_control), so a sweep over all
+// trees is a pure launch sequence with no host round trip.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "sampler_core.hpp"
+
+namespace s4b {
+
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);     \
+  } while (0)
+
+constexpr int BLOCK = 256;          // 4 waves
+constexpr int GRID_MAX = 1024;      // workgroups of the O(N) kernels (4 per CU)
+constexpr int NBMAX = 16;           // bins accumulated in registers per pass
+
+// ------------------------------------------------------------------------------------------------
+// wave / block reductions with a fixed order (deterministic)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_stats: one pass over (R, leaf_t, [xbin columns of the proposal]) -> per-workgroup (count, sum) of the
+// partial residual r_i = R_i + mu_t[leaf_t(i)] for the A bins (current leaves) and the B bins (leaves the
+// pending proposal would create under its root).
+struct StatsTables {   // LDS image, entries valid for node ids < hwm
+  double* mu; int16_t* binA; int16_t* binB; int16_t* pvar; uint16_t* pcut; int16_t* pleft; int16_t* pright; uint8_t* insub;
+};
+
+__device__ __forceinline__ StatsTables carve_stats(unsigned char* base, int nc) {
+  StatsTables s;
+  s.mu = (double*)base; base += (size_t)nc * 8;
+  s.binA = (int16_t*)base; base += (size_t)nc * 2;
+  s.binB = (int16_t*)base; base += (size_t)nc * 2;
+  s.pvar = (int16_t*)base; base += (size_t)nc * 2;
+  s.pcut = (uint16_t*)base; base += (size_t)nc * 2;
+  s.pleft = (int16_t*)base; base += (size_t)nc * 2;
+  s.pright = (int16_t*)base; base += (size_t)nc * 2;
+  s.insub = (uint8_t*)base;
+  return s;
+}
+static size_t stats_lds_bytes(int nc) { return ((size_t)nc * (8 + 6 * 2 + 1) + 15) / 16 * 16 + 2 * 4 * NBMAX * 8; }
+
+template <int NB>
+__device__ __forceinline__ void stats_pass(const BartArrays& a, int t, const StatsTables& L, int root, int base, int nbTotal,
+                                           double* redS, double* redN) {
+  double accS[NB], accN[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) { accS[k] = 0.0; accN[k] = 0.0; }
+  const int64_t nQuads = (a.n + 3) >> 2;
+  const uint16_t* __restrict__ leafPlane = a.leaf + (size_t)t * a.npad;
+  const double* __restrict__ R = a.R;
+  for (int64_t qd = (int64_t)blockIdx.x * BLOCK + threadIdx.x; qd < nQuads; qd += (int64_t)gridDim.x * BLOCK) {
+    const int64_t i0 = qd << 2;
+    const double2 r01 = *reinterpret_cast<const double2*>(R + i0);
+    const double2 r23 = *reinterpret_cast<const double2*>(R + i0 + 2);
+    const ushort4 lf4 = *reinterpret_cast<const ushort4*>(leafPlane + i0);
+    const double rr[4] = {r01.x, r01.y, r23.x, r23.y};
+    const unsigned lf[4] = {lf4.x, lf4.y, lf4.z, lf4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (i0 + e >= a.n) break;
+      const unsigned l = lf[e];
+      const double r = rr[e] + L.mu[l];
+      const int ba = (int)L.binA[l] - base;
+      int bb = -1 - base;
+      if (L.insub[l]) {
+        int nd = root;
+        int v = L.pvar[nd];
+        while (v >= 0) {
+          const unsigned x = a.xbin[(size_t)v * a.npad + (size_t)(i0 + e)];
+          nd = (x <= (unsigned)L.pcut[nd]) ? L.pleft[nd] : L.pright[nd];
+          v = L.pvar[nd];
+        }
+        bb = (int)L.binB[nd] - base;
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const bool m = (ba == k) | (bb == k);
+        accS[k] += m ? r : 0.0;
+        accN[k] += m ? 1.0 : 0.0;
+      }
+    }
+  }
+  // block reduction, fixed order: xor-butterfly inside each wave, then waves 0..3 in order
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const double s = wave_sum(accS[k]), c = wave_sum(accN[k]);
+    if (lane == 0) { redS[wv * NBMAX + k] = s; redN[wv * NBMAX + k] = c; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NB && base + (int)threadIdx.x < nbTotal) {
+    const int k = threadIdx.x;
+    const double s = ((redS[k] + redS[NBMAX + k]) + redS[2 * NBMAX + k]) + redS[3 * NBMAX + k];
+    const double c = ((redN[k] + redN[NBMAX + k]) + redN[2 * NBMAX + k]) + redN[3 * NBMAX + k];
+    a.partSum[(size_t)(base + k) * a.grid + blockIdx.x] = s;
+    a.partCnt[(size_t)(base + k) * a.grid + blockIdx.x] = c;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(BLOCK) void k_stats(BartArrays a, int t) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const StepScratch& c = a.sc[t & 1];
+  const Proposal pr = *c.prop;
+  StatsTables L = carve_stats(smem, a.nc);
+  double* redS = (double*)(smem + ((size_t)a.nc * 21 + 15) / 16 * 16);
+  double* redN = redS + 4 * NBMAX;
+  const double* mu = a.mu + (size_t)t * a.nc;
+  for (int i = threadIdx.x; i < pr.hwm; i += BLOCK) {
+    L.mu[i] = mu[i]; L.binA[i] = c.binA[i]; L.binB[i] = c.binB[i]; L.pvar[i] = c.pvar[i]; L.pcut[i] = c.pcut[i];
+    L.pleft[i] = c.pleft[i]; L.pright[i] = c.pright[i]; L.insub[i] = c.insub[i];
+  }
+  __syncthreads();
+  const int nb = pr.nbA + pr.nbB;
+  if (nb <= 4) stats_pass<4>(a, t, L, pr.node, 0, nb, redS, redN);
+  else if (nb <= 8) stats_pass<8>(a, t, L, pr.node, 0, nb, redS, redN);
+  else for (int base = 0; base < nb; base += NBMAX) stats_pass<NBMAX>(a, t, L, pr.node, base, nb, redS, redN);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_control: combines the per-workgroup partials in a fixed order, then lane 0 runs the Metropolis-Hastings
+// control code (decide tree t, draw its leaves, draw the proposal of the next tree) on LDS-staged copies.
+struct ControlLds {
+  // staged arrays for the tree being decided (cur) and, optionally, the next tree to propose
+  int16_t *var, *left, *right, *parent; uint16_t* cut; double* mu; int32_t* cnt;
+  int16_t *pvar, *pleft, *pright, *pparent; uint16_t* pcut; int16_t *binA, *binB, *list; uint8_t* insub; double* muOld;
+};
+static size_t control_lds_bytes(int nc, int P) {
+  // two tree images (decided tree + next tree): 5 x 2 B structure, mu 8, cnt 4, proposal tables 8 x 2 + 1, muOld 8
+  size_t per = (size_t)nc * (10 + 8 + 4 + 16 + 1 + 8) + 17 * 16 + 2 * sizeof(Proposal);
+  return 2 * per + (size_t)2 * nc * 16 /*bins*/ + sizeof(MTState) + (size_t)P * 4 + 512;
+}
+
+__device__ __forceinline__ unsigned char* carve(unsigned char*& p, size_t bytes) {
+  unsigned char* r = p; p += (bytes + 15) / 16 * 16; return r;
+}
+
+__device__ void stage_tree(int nc, const StepCtx& g, StepCtx& l, unsigned char*& p) {
+  // g: context on the global arrays, l: the same shapes carved out of LDS
+  l = g;
+  l.cur.var = (int16_t*)carve(p, (size_t)nc * 2); l.cur.cut = (uint16_t*)carve(p, (size_t)nc * 2);
+  l.cur.left = (int16_t*)carve(p, (size_t)nc * 2); l.cur.right = (int16_t*)carve(p, (size_t)nc * 2);
+  l.cur.parent = (int16_t*)carve(p, (size_t)nc * 2);
+  l.mu = (double*)carve(p, (size_t)nc * 8); l.cnt = (int32_t*)carve(p, (size_t)nc * 4);
+  l.tb.prop.var = (int16_t*)carve(p, (size_t)nc * 2); l.tb.prop.cut = (uint16_t*)carve(p, (size_t)nc * 2);
+  l.tb.prop.left = (int16_t*)carve(p, (size_t)nc * 2); l.tb.prop.right = (int16_t*)carve(p, (size_t)nc * 2);
+  l.tb.prop.parent = (int16_t*)carve(p, (size_t)nc * 2);
+  l.tb.binA = (int16_t*)carve(p, (size_t)nc * 2); l.tb.binB = (int16_t*)carve(p, (size_t)nc * 2);
+  l.tb.list = (int16_t*)carve(p, (size_t)nc * 2); l.tb.insub = (uint8_t*)carve(p, (size_t)nc);
+  l.muOld = (double*)carve(p, (size_t)nc * 8);
+  l.prop = (Proposal*)carve(p, sizeof(Proposal));
+}
+
+__device__ void copy_tree_in(const StepCtx& g, StepCtx& l, int count, bool withTables) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    l.cur.var[i] = g.cur.var[i]; l.cur.cut[i] = g.cur.cut[i]; l.cur.left[i] = g.cur.left[i]; l.cur.right[i] = g.cur.right[i];
+    l.cur.parent[i] = g.cur.parent[i]; l.mu[i] = g.mu[i]; l.cnt[i] = g.cnt[i];
+    if (withTables) {
+      l.tb.prop.var[i] = g.tb.prop.var[i]; l.tb.prop.cut[i] = g.tb.prop.cut[i]; l.tb.prop.left[i] = g.tb.prop.left[i];
+      l.tb.prop.right[i] = g.tb.prop.right[i]; l.tb.prop.parent[i] = g.tb.prop.parent[i];
+      l.tb.binA[i] = g.tb.binA[i]; l.tb.binB[i] = g.tb.binB[i]; l.tb.insub[i] = g.tb.insub[i];
+    }
+  }
+}
+__device__ void copy_tree_out(const StepCtx& l, StepCtx& g, int count, bool curAndMu, bool tables) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    if (curAndMu) {
+      g.cur.var[i] = l.cur.var[i]; g.cur.cut[i] = l.cur.cut[i]; g.cur.left[i] = l.cur.left[i]; g.cur.right[i] = l.cur.right[i];
+      g.cur.parent[i] = l.cur.parent[i]; g.mu[i] = l.mu[i]; g.cnt[i] = l.cnt[i]; g.muOld[i] = l.muOld[i]; g.tb.insub[i] = l.tb.insub[i];
+    }
+    if (tables) {
+      g.tb.prop.var[i] = l.tb.prop.var[i]; g.tb.prop.cut[i] = l.tb.prop.cut[i]; g.tb.prop.left[i] = l.tb.prop.left[i];
+      g.tb.prop.right[i] = l.tb.prop.right[i]; g.tb.prop.parent[i] = l.tb.prop.parent[i];
+      g.tb.binA[i] = l.tb.binA[i]; g.tb.binB[i] = l.tb.binB[i]; g.tb.insub[i] = l.tb.insub[i];
+    }
+  }
+}
+
+// mode: bit0 = decide tree t (requires reduced partials), bit1 = propose tree `next`
+__global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next, int useLds) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool doDecide = t >= 0;
+  if (!useLds) {   // tree too large to stage: run straight on the global arrays
+    if (doDecide) {
+      const Proposal* pr = a.sc[t & 1].prop;
+      const int nb = pr->nbA + pr->nbB;
+      for (int k = wv; k < nb; k += BLOCK / 64) {
+        double s = 0.0, c = 0.0;
+        for (int b = lane; b < a.grid; b += 64) { s += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
+        s = wave_sum(s); c = wave_sum(c);
+        if (lane == 0) { a.binSum[k] = s; a.binCnt[k] = c; }
+      }
+      __threadfence();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (doDecide) control_step(a, t, next); else propose_step(a, next);
+    }
+    return;
+  }
+  unsigned char* p = smem;
+  double* binSum = (double*)carve(p, (size_t)2 * a.nc * 8);
+  double* binCnt = (double*)carve(p, (size_t)2 * a.nc * 8);
+  MTState* rng = (MTState*)carve(p, sizeof(MTState));
+  int32_t* numCuts = (int32_t*)carve(p, (size_t)a.P * 4);
+  int32_t* s_hwm = (int32_t*)carve(p, 16);   // [0] entries to write back for tree t, [1] for tree `next`
+  StepCtx gT, lT, gN, lN;
+  if (doDecide) { gT = step_ctx(a, t); stage_tree(a.nc, gT, lT, p); }
+  if (next >= 0) { gN = step_ctx(a, next); stage_tree(a.nc, gN, lN, p); }
+  // ---- stage in
+  for (int i = threadIdx.x; i < (int)(sizeof(MTState) / 4); i += BLOCK) ((uint32_t*)rng)[i] = ((const uint32_t*)a.rng)[i];
+  for (int i = threadIdx.x; i < a.P; i += BLOCK) numCuts[i] = a.numCuts[i];
+  if (doDecide) {
+    if (threadIdx.x == 0) *lT.prop = *gT.prop;
+    __syncthreads();
+    const int cnt = lT.prop->hwm;   // proposal tables are valid up to the proposal's hwm (>= tree hwm)
+    copy_tree_in(gT, lT, cnt, true);
+    const int nb = lT.prop->nbA + lT.prop->nbB;
+    for (int k = wv; k < nb; k += BLOCK / 64) {
+      double s = 0.0, c = 0.0;
+      for (int b = lane; b < a.grid; b += 64) { s += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
+      s = wave_sum(s); c = wave_sum(c);
+      if (lane == 0) { binSum[k] = s; binCnt[k] = c; }
+    }
+  }
+  if (next >= 0) copy_tree_in(gN, lN, gN.hwm, false);
+  __syncthreads();
+  // ---- one lane: the sequential Metropolis-Hastings control code
+  if (threadIdx.x == 0) {
+    ModelView m = a.model; m.numCuts = numCuts;
+    if (doDecide) {
+      StepRecord rec;
+      lT.hwm = gT.hwm;
+      ctx_decide(lT, m, a.scale->sigma, rng, binCnt, binSum, a.traceOn ? &rec : nullptr);
+      a.hwm[t] = lT.hwm;
+      if (a.traceOn) push_trace(a, rec);
+      s_hwm[0] = lT.prop->hwm > lT.hwm ? lT.prop->hwm : lT.hwm;
+    }
+    if (next >= 0) {
+      lN.hwm = gN.hwm;
+      ctx_propose(lN, m, rng, a.errFlag);
+      *gN.prop = *lN.prop;
+      s_hwm[1] = lN.prop->hwm;
+    }
+  }
+  __syncthreads();
+  // ---- stage out
+  for (int i = threadIdx.x; i < (int)(sizeof(MTState) / 4); i += BLOCK) ((uint32_t*)a.rng)[i] = ((const uint32_t*)rng)[i];
+  if (doDecide) copy_tree_out(lT, gT, s_hwm[0], true, false);
+  if (next >= 0) copy_tree_out(lN, gN, s_hwm[1], false, true);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_apply: R_i += mu_old[leaf] - mu_new[leaf'], relabel observations under the accepted move's root
+__global__ __launch_bounds__(BLOCK) void k_apply(BartArrays a, int t) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const StepScratch& c = a.sc[t & 1];
+  const int acc = *c.accepted;
+  const int root = c.prop->node;
+  const int hwm = c.prop->hwm > a.hwm[t] ? c.prop->hwm : a.hwm[t];
+  const int nc = a.nc;
+  double* muOld = (double*)smem; double* muNew = muOld + nc;
+  int16_t* var = (int16_t*)(muNew + nc); uint16_t* cut = (uint16_t*)(var + nc); int16_t* left = (int16_t*)(cut + nc); int16_t* right = left + nc;
+  uint8_t* insub = (uint8_t*)(right + nc);
+  const size_t o = (size_t)t * nc;
+  for (int i = threadIdx.x; i < hwm; i += BLOCK) {
+    muOld[i] = c.muOld[i]; muNew[i] = a.mu[o + i]; var[i] = a.var[o + i]; cut[i] = a.cut[o + i]; left[i] = a.left[o + i]; right[i] = a.right[o + i];
+    insub[i] = c.insub[i];
+  }
+  __syncthreads();
+  const int64_t nQuads = (a.n + 3) >> 2;
+  uint16_t* __restrict__ leafPlane = a.leaf + (size_t)t * a.npad;
+  double* __restrict__ R = a.R;
+  for (int64_t qd = (int64_t)blockIdx.x * BLOCK + threadIdx.x; qd < nQuads; qd += (int64_t)gridDim.x * BLOCK) {
+    const int64_t i0 = qd << 2;
+    double2 r01 = *reinterpret_cast<const double2*>(R + i0);
+    double2 r23 = *reinterpret_cast<const double2*>(R + i0 + 2);
+    ushort4 lf4 = *reinterpret_cast<const ushort4*>(leafPlane + i0);
+    double rr[4] = {r01.x, r01.y, r23.x, r23.y};
+    unsigned lf[4] = {lf4.x, lf4.y, lf4.z, lf4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (i0 + e >= a.n) break;
+      const unsigned l = lf[e];
+      unsigned nl = l;
+      if (acc && insub[l]) {
+        int nd = root;
+        int v = var[nd];
+        while (v >= 0) {
+          const unsigned x = a.xbin[(size_t)v * a.npad + (size_t)(i0 + e)];
+          nd = (x <= (unsigned)cut[nd]) ? left[nd] : right[nd];
+          v = var[nd];
+        }
+        nl = (unsigned)nd;
+      }
+      rr[e] = (rr[e] + muOld[l]) - muNew[nl];
+      lf[e] = nl;
+    }
+    *reinterpret_cast<double2*>(R + i0) = make_double2(rr[0], rr[1]);
+    *reinterpret_cast<double2*>(R + i0 + 2) = make_double2(rr[2], rr[3]);
+    if (acc) *reinterpret_cast<ushort4*>(leafPlane + i0) = make_ushort4((unsigned short)lf[0], (unsigned short)lf[1], (unsigned short)lf[2], (unsigned short)lf[3]);
+  }
+}
+static size_t apply_lds_bytes(int nc) { return (size_t)nc * (16 + 8 + 1) + 16; }
+
+// ------------------------------------------------------------------------------------------------
+// tree initialisation: full traversal for every tree, residual from scratch
+__global__ __launch_bounds__(BLOCK) void k_assign_leaves(BartArrays a) {
+  const ScaleState sc = *a.scale;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK) {
+    double r = (a.y[i] - a.off[i] - sc.min) / sc.range - 0.5;
+    for (int t = 0; t < a.T; ++t) {
+      const size_t o = (size_t)t * a.nc;
+      int nd = 0;
+      int v = a.var[o];
+      while (v >= 0) {
+        const unsigned x = a.xbin[(size_t)v * a.npad + (size_t)i];
+        nd = (x <= (unsigned)a.cut[o + nd]) ? a.left[o + nd] : a.right[o + nd];
+        v = a.var[o + nd];
+      }
+      a.leaf[(size_t)t * a.npad + (size_t)i] = (uint16_t)nd;
+      r -= a.mu[o + nd];
+    }
+    a.R[i] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// offsets / response rescaling
+struct StanArrays {
+  int32_t K, q; int64_t nnz;
+  const double* X;          // [K][n]
+  const double* w; const int32_t* v; const int32_t* u;   // CSR of Z
+  // CSC of Z in fixed chunks for the deterministic Z'e
+  const int32_t* cscRow; const double* cscVal; const int32_t* chunkCol; const int64_t* chunkStart; const int32_t* chunkLen; int32_t numChunks;
+  const int32_t* colChunkPtr;   // [q+1] chunk range of every column
+  double* params;           // [K + q] beta, b (device copy)
+  double* e0;               // [n]  y - stanOffset
+  double* e;                // [n]  per-leapfrog residual (hmc_mode 1) / scratch
+  double* train;            // [n]  BART fit on the data scale
+  double* part;             // [(1 + K)][grid] partial sums
+  double* chunkPart;        // [numChunks]
+  double* out;              // [1 + K + q] reduced: ss, X'e, Z'e
+  double* mmPart;           // [2][grid] min / max partials
+};
+
+__device__ __forceinline__ double param_mean_at(const StanArrays& s, int64_t n, int64_t i, int fixed, int random) {
+  double eta = 0.0;
+  if (fixed) for (int k = 0; k < s.K; ++k) eta += s.X[(size_t)k * n + i] * s.params[k];
+  if (random && s.q) for (int e = s.u[i]; e < s.u[i + 1]; ++e) eta += s.w[e] * s.params[s.K + s.v[e]];
+  return eta;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_param_mean(BartArrays a, StanArrays s, int fixed, int random, int addUser, int fromHost, double* dst) {
+  double mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK) {
+    double eta;
+    if (fromHost) eta = dst[i];
+    else { eta = param_mean_at(s, a.n, i, fixed, random); if (addUser) eta += a.userOffset[i]; dst[i] = eta; }
+    const double v = a.y[i] - eta;
+    mn = fmin(mn, v); mx = fmax(mx, v);
+  }
+  __shared__ double smn[4], smx[4];
+  mn = wave_min(mn); mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s.mmPart[blockIdx.x] = fmin(fmin(smn[0], smn[1]), fmin(smn[2], smn[3]));
+    s.mmPart[a.grid + blockIdx.x] = fmax(fmax(smx[0], smx[1]), fmax(smx[2], smx[3]));
+  }
+}
+
+// one wave: new scale (when update) + sigma on the rescaled scale; then rescales every leaf value
+__global__ void k_scale(BartArrays a, StanArrays s, int update, int gridUsed) {
+  __shared__ ScaleState sh;
+  if (threadIdx.x == 0) {
+    ScaleState sc = *a.scale;
+    sc.min0 = sc.min; sc.range0 = sc.range; sc.shiftPerTree = 0.0;
+    if (update) {
+      double mn = INFINITY, mx = -INFINITY;
+      for (int b = 0; b < gridUsed; ++b) { mn = fmin(mn, s.mmPart[b]); mx = fmax(mx, s.mmPart[a.grid + b]); }
+      sc.min = mn; sc.max = mx; sc.range = mx - mn;
+      sc.shiftPerTree = (sc.min0 + 0.5 * sc.range0 - sc.min - 0.5 * sc.range) / (double)a.T;
+    }
+    sc.sigma = sc.sigmaData / sc.range;
+    *a.scale = sc; sh = sc;
+  }
+  __syncthreads();
+  if (update) {
+    const ScaleState sc = sh;
+    const size_t m = (size_t)a.T * a.nc;
+    for (size_t k = threadIdx.x; k < m; k += blockDim.x) a.mu[k] = (sc.range0 * a.mu[k] + sc.shiftPerTree) / sc.range;
+  }
+}
+
+__global__ void k_set_sigma(BartArrays a, double sigmaData) {
+  a.scale->sigmaData = sigmaData; a.scale->sigma = sigmaData / a.scale->range;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_rescale(BartArrays a, int update) {
+  const ScaleState sc = *a.scale;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK) {
+    const double y = a.y[i];
+    const double yOld = (y - a.off[i] - sc.min0) / sc.range0 - 0.5;
+    double F = yOld - a.R[i];
+    if (update) F = (sc.range0 * F + (double)a.T * sc.shiftPerTree) / sc.range;
+    const double yNew = (y - a.offNew[i] - sc.min) / sc.range - 0.5;
+    a.R[i] = yNew - F;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_init_residual(BartArrays a) {   // all tree fits zero: R = yRescaled
+  const ScaleState sc = *a.scale;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK)
+    a.R[i] = (a.y[i] - a.off[i] - sc.min) / sc.range - 0.5;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stan inputs: e0 = y - stanOffset, |e0|^2, X'e0 (fixed-order partials); optional BART fit output
+template <int KC>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[KC], int kBase, int kCount, double* part, int grid) {
+  __shared__ double red[4][KC];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < KC; ++k) { const double s = wave_sum(acc[k]); if (lane == 0) red[wv][k] = s; }
+  __syncthreads();
+  if ((int)threadIdx.x < KC && (int)threadIdx.x < kCount) {
+    const int k = threadIdx.x;
+    part[(size_t)(kBase + k) * grid + blockIdx.x] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+  }
+  __syncthreads();
+}
+
+// mode 0: e = y; 1: y - fit; 2: y - user; 3: y - (fit + user).   direct = 1: e = e0 - X beta - Z b (leapfrog)
+__global__ __launch_bounds__(BLOCK) void k_stan_inputs(BartArrays a, StanArrays s, int mode, int wantTrain, int direct) {
+  const ScaleState sc = *a.scale;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};   // ss, X'e for the first 3 columns
+  double* dstE = direct ? s.e : s.e0;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK) {
+    double e;
+    if (direct) e = s.e0[i] - param_mean_at(s, a.n, i, 1, 1);
+    else {
+      double fit = 0.0;
+      if (mode != 0 || wantTrain) {
+        const double yr = (a.y[i] - a.off[i] - sc.min) / sc.range - 0.5;
+        fit = ((yr - a.R[i]) + 0.5) * sc.range + sc.min;
+      }
+      const double so = mode == 0 ? 0.0 : mode == 1 ? fit : mode == 2 ? a.userOffset[i] : fit + a.userOffset[i];
+      e = a.y[i] - so;
+      if (wantTrain) s.train[i] = fit;
+    }
+    dstE[i] = e;
+    acc[0] += e * e;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (k < s.K) acc[1 + k] += s.X[(size_t)k * a.n + i] * e;
+  }
+  block_reduce_store<4>(acc, 0, 1 + (s.K < 3 ? s.K : 3), s.part, a.grid);
+}
+
+// remaining columns of X'e (K > 3), four per launch
+__global__ __launch_bounds__(BLOCK) void k_xt_e(BartArrays a, StanArrays s, int k0, int direct) {
+  const double* src = direct ? s.e : s.e0;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK) {
+    const double e = src[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k0 + k < s.K) acc[k] += s.X[(size_t)(k0 + k) * a.n + i] * e;
+  }
+  block_reduce_store<4>(acc, 1 + k0, (s.K - k0) < 4 ? (s.K - k0) : 4, s.part, a.grid);
+}
+
+// Z'e: one workgroup per fixed chunk of one CSC column; rows of a column are ascending, so the gathers of e
+// walk memory forward
+__global__ __launch_bounds__(BLOCK) void k_zt_chunks(StanArrays s, int direct) {
+  const double* src = direct ? s.e : s.e0;
+  const int c = blockIdx.x;
+  const int64_t st = s.chunkStart[c];
+  const int len = s.chunkLen[c];
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < len; j += BLOCK) acc += s.cscVal[st + j] * src[s.cscRow[st + j]];
+  __shared__ double red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) s.chunkPart[c] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// final fixed-order combination: out[0] = ss, out[1..K] = X'e, out[1+K..] = Z'e
+__global__ __launch_bounds__(BLOCK) void k_stan_finalize(BartArrays a, StanArrays s, int gridUsed) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k = wv; k < 1 + s.K; k += BLOCK / 64) {
+    double v = 0.0;
+    for (int b = lane; b < gridUsed; b += 64) v += s.part[(size_t)k * a.grid + b];
+    v = wave_sum(v);
+    if (lane == 0) s.out[k] = v;
+  }
+  for (int j = threadIdx.x; j < s.q; j += BLOCK) {
+    double v = 0.0;
+    for (int c = s.colChunkPtr[j]; c < s.colChunkPtr[j + 1]; ++c) v += s.chunkPart[c];
+    s.out[1 + s.K + j] = v;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_test_fits(BartArrays a, double* out) {
+  const ScaleState sc = *a.scale;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.nTest; i += (int64_t)gridDim.x * BLOCK) {
+    double f = 0.0;
+    for (int t = 0; t < a.T; ++t) {
+      const size_t o = (size_t)t * a.nc;
+      int nd = 0, v = a.var[o];
+      while (v >= 0) {
+        const unsigned x = a.xbinTest[(size_t)v * a.nTestPad + (size_t)i];
+        nd = (x <= (unsigned)a.cut[o + nd]) ? a.left[o + nd] : a.right[o + nd];
+        v = a.var[o + nd];
+      }
+      f += a.mu[o + nd];
+    }
+    out[i] = (f + 0.5) * sc.range + sc.min;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+class DevHip {
+ public:
+  DevHip() {}
+  ~DevHip() {
+    for (void* p : allocs_) (void)hipFree(p);
+    if (pinned_) (void)hipHostFree(pinned_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+    if (evStart_) { (void)hipEventDestroy(evStart_); (void)hipEventDestroy(evStop_); }
+  }
+  DevHip(const DevHip&) = delete;
+
+  void init(const DevInit& d) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+      throw std::runtime_error("stan4bart_amd: no HIP device available — the MI355X path has no CPU fallback");
+    if (d.device < 0 || d.device >= count) throw std::runtime_error("stan4bart_amd: HIP device ordinal out of range");
+    device_ = d.device;
+    HIP_OK(hipSetDevice(device_));
+    HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_OK(hipEventCreate(&evStart_)); HIP_OK(hipEventCreate(&evStop_));
+    n_ = d.n; nTest_ = d.nTest; P_ = d.P; T_ = d.T; nc_ = d.nc; K_ = d.K; q_ = d.q;
+    BartArrays& a = a_;
+    a = BartArrays{};
+    a.n = n_; a.npad = (n_ + 7) / 8 * 8; a.P = P_; a.T = T_; a.nc = nc_; a.nTest = nTest_; a.nTestPad = (nTest_ + 7) / 8 * 8;
+    const int64_t nQuads = (n_ + 3) / 4;
+    a.grid = (int)std::min<int64_t>(GRID_MAX, std::max<int64_t>(1, (nQuads + BLOCK - 1) / BLOCK));
+    a.binCap = 2 * nc_; a.traceCap = d.traceCap;
+    // ---- observation-length arrays
+    uint16_t* xb = alloc<uint16_t>((size_t)P_ * a.npad);
+    HIP_OK(hipMemsetAsync(xb, 0, (size_t)P_ * a.npad * 2, stream_));
+    HIP_OK(hipMemcpy2DAsync(xb, (size_t)a.npad * 2, d.xbin, (size_t)n_ * 2, (size_t)n_ * 2, (size_t)P_, hipMemcpyHostToDevice, stream_));
+    a.xbin = xb;
+    if (nTest_) {
+      uint16_t* xt = alloc<uint16_t>((size_t)P_ * a.nTestPad);
+      HIP_OK(hipMemcpy2DAsync(xt, (size_t)a.nTestPad * 2, d.xbinTest, (size_t)nTest_ * 2, (size_t)nTest_ * 2, (size_t)P_, hipMemcpyHostToDevice, stream_));
+      a.xbinTest = xt;
+    }
+    double* y = alloc<double>((size_t)a.npad); upload(y, d.y, (size_t)n_); a.y = y;
+    a.R = alloc<double>((size_t)a.npad); HIP_OK(hipMemsetAsync(a.R, 0, (size_t)a.npad * 8, stream_));
+    a.off = alloc<double>((size_t)a.npad); HIP_OK(hipMemsetAsync(a.off, 0, (size_t)a.npad * 8, stream_));
+    a.offNew = alloc<double>((size_t)a.npad); HIP_OK(hipMemsetAsync(a.offNew, 0, (size_t)a.npad * 8, stream_));
+    if (d.userOffset) { double* uo = alloc<double>((size_t)a.npad); upload(uo, d.userOffset, (size_t)n_); a.userOffset = uo; }
+    a.leaf = alloc<uint16_t>((size_t)T_ * a.npad); HIP_OK(hipMemsetAsync(a.leaf, 0, (size_t)T_ * a.npad * 2, stream_));
+    // ---- trees
+    const size_t m = (size_t)T_ * nc_;
+    a.var = alloc<int16_t>(m); a.left = alloc<int16_t>(m); a.right = alloc<int16_t>(m); a.parent = alloc<int16_t>(m); a.cut = alloc<uint16_t>(m);
+    a.mu = alloc<double>(m); a.cnt = alloc<int32_t>(m); a.hwm = alloc<int32_t>((size_t)T_);
+    {
+      std::vector<int16_t> var(m, NODE_FREE), neg(m, -1); std::vector<int32_t> hwm((size_t)T_, 1);
+      for (int t = 0; t < T_; ++t) var[(size_t)t * nc_] = NODE_LEAF;
+      upload(a.var, var.data(), m); upload(a.left, neg.data(), m); upload(a.right, neg.data(), m); upload(a.parent, neg.data(), m);
+      HIP_OK(hipMemsetAsync(a.cut, 0, m * 2, stream_)); HIP_OK(hipMemsetAsync(a.mu, 0, m * 8, stream_)); HIP_OK(hipMemsetAsync(a.cnt, 0, m * 4, stream_));
+      upload(a.hwm, hwm.data(), (size_t)T_);
+      HIP_OK(hipStreamSynchronize(stream_));
+    }
+    for (int s = 0; s < 2; ++s) {
+      StepScratch& c = a.sc[s];
+      c.pvar = zalloc<int16_t>(nc_); c.pleft = zalloc<int16_t>(nc_); c.pright = zalloc<int16_t>(nc_); c.pparent = zalloc<int16_t>(nc_); c.pcut = zalloc<uint16_t>(nc_);
+      c.binA = zalloc<int16_t>(nc_); c.binB = zalloc<int16_t>(nc_); c.list = zalloc<int16_t>(nc_); c.insub = zalloc<uint8_t>(nc_);
+      c.muOld = zalloc<double>(nc_); c.prop = zalloc<Proposal>(1); c.accepted = zalloc<int32_t>(1);
+    }
+    a.partCnt = zalloc<double>((size_t)a.binCap * a.grid); a.partSum = zalloc<double>((size_t)a.binCap * a.grid);
+    a.binCnt = zalloc<double>((size_t)a.binCap); a.binSum = zalloc<double>((size_t)a.binCap);
+    a.rng = zalloc<MTState>(1); a.scale = zalloc<ScaleState>(1);
+    int32_t* nc = alloc<int32_t>((size_t)P_); upload(nc, d.numCuts, (size_t)P_); a.numCuts = nc;
+    a.trace = zalloc<StepRecord>((size_t)std::max(1, d.traceCap)); a.traceCount = zalloc<int32_t>(1); a.errFlag = zalloc<int32_t>(1);
+    a.model = d.model; a.model.numCuts = nc; a.traceOn = 0;
+    // ---- Stan-side arrays
+    StanArrays& s = s_;
+    s = StanArrays{};
+    s.K = K_; s.q = q_; s.nnz = d.nnz;
+    if (K_) { double* X = alloc<double>((size_t)K_ * n_); upload(X, d.X, (size_t)K_ * n_); s.X = X; }
+    { int32_t* u = alloc<int32_t>((size_t)n_ + 1);
+      if (d.u) upload(u, d.u, (size_t)n_ + 1); else HIP_OK(hipMemsetAsync(u, 0, ((size_t)n_ + 1) * 4, stream_));
+      s.u = u; }
+    if (d.nnz) {
+      double* w = alloc<double>((size_t)d.nnz); upload(w, d.w, (size_t)d.nnz); s.w = w;
+      int32_t* v = alloc<int32_t>((size_t)d.nnz); upload(v, d.v, (size_t)d.nnz); s.v = v;
+      build_csc(d);
+    } else {
+      std::vector<int32_t> ptr((size_t)q_ + 1, 0);
+      int32_t* cp = alloc<int32_t>((size_t)q_ + 1); upload(cp, ptr.data(), (size_t)q_ + 1); s.colChunkPtr = cp;
+      HIP_OK(hipStreamSynchronize(stream_));
+    }
+    s.params = zalloc<double>((size_t)std::max(1, K_ + q_));
+    s.e0 = zalloc<double>((size_t)a.npad); s.e = zalloc<double>((size_t)a.npad); s.train = zalloc<double>((size_t)a.npad);
+    s.part = zalloc<double>((size_t)(1 + K_) * a.grid);
+    s.out = zalloc<double>((size_t)(1 + K_ + q_));
+    s.mmPart = zalloc<double>((size_t)2 * a.grid);
+    HIP_OK(hipHostMalloc(&pinned_, sizeof(double) * (size_t)(2 * (1 + K_ + q_) + 64), hipHostMallocDefault));
+    if (nTest_) testOut_ = zalloc<double>((size_t)nTest_);
+    // ---- launch configuration
+    gridN_ = (int)std::min<int64_t>(GRID_MAX, std::max<int64_t>(1, (n_ + BLOCK - 1) / BLOCK));
+    ldsStats_ = stats_lds_bytes(nc_); ldsApply_ = apply_lds_bytes(nc_); ldsControl_ = control_lds_bytes(nc_, P_);
+    useLds_ = ldsControl_ <= 150 * 1024 ? 1 : 0;
+    if (ldsStats_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsStats_));
+    if (ldsApply_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsApply_));
+    if (useLds_ && ldsControl_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_control), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsControl_));
+    if (ldsStats_ > 160 * 1024 || ldsApply_ > 160 * 1024) throw std::runtime_error("node_capacity too large for the 160 KiB LDS of a CU");
+    // ---- initial scale from the raw response (offset 0), R = yRescaled
+    hipLaunchKernelGGL(k_param_mean, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, 0, 0, 0, 1, a_.offNew); ++launches_;
+    hipLaunchKernelGGL(k_scale, dim3(1), dim3(BLOCK), 0, stream_, a_, s_, 1, gridN_); ++launches_;
+    HIP_OK(hipMemsetAsync(a_.mu, 0, (size_t)T_ * nc_ * 8, stream_));   // the very first scale has no tree fits to carry over
+    hipLaunchKernelGGL(k_init_residual, dim3(gridN_), dim3(BLOCK), 0, stream_, a_); ++launches_;
+    sync();
+  }
+
+  // ---- small transfers
+  void upload_rng(const MTState& s) { HIP_OK(hipMemcpyAsync(a_.rng, &s, sizeof(MTState), hipMemcpyHostToDevice, stream_)); sync(); }
+  void download_rng(MTState& s) { HIP_OK(hipMemcpyAsync(&s, a_.rng, sizeof(MTState), hipMemcpyDeviceToHost, stream_)); sync(); }
+  void upload_trees(const int16_t* var, const uint16_t* cut, const int16_t* left, const int16_t* right, const int16_t* parent, const double* mu, const int32_t* hwm) {
+    const size_t m = (size_t)T_ * nc_;
+    upload(a_.var, var, m); upload(a_.cut, cut, m); upload(a_.left, left, m); upload(a_.right, right, m); upload(a_.parent, parent, m);
+    upload(a_.mu, mu, m); upload(a_.hwm, hwm, (size_t)T_);
+    sync();
+  }
+  void download_trees(int16_t* var, uint16_t* cut, int16_t* left, int16_t* right, int16_t* parent, double* mu, int32_t* cnt, int32_t* hwm) {
+    const size_t m = (size_t)T_ * nc_;
+    download(var, a_.var, m); download(cut, a_.cut, m); download(left, a_.left, m); download(right, a_.right, m); download(parent, a_.parent, m);
+    download(mu, a_.mu, m); download(cnt, a_.cnt, m); download(hwm, a_.hwm, (size_t)T_);
+    sync();
+  }
+  void download_leaf_plane(int t, uint16_t* out) { download(out, a_.leaf + (size_t)t * a_.npad, (size_t)n_); sync(); }
+  void get_scale(ScaleState& s) { download(&s, a_.scale, 1); sync(); }
+  int32_t error_flags() { int32_t e = 0; download(&e, a_.errFlag, 1); sync(); return e; }
+  int64_t launches() const { return launches_; }
+  void set_trace(bool on) { a_.traceOn = on ? 1 : 0; HIP_OK(hipMemsetAsync(a_.traceCount, 0, 4, stream_)); sync(); }
+  int64_t get_trace(int64_t cap, int32_t* out) {
+    int32_t m = 0; download(&m, a_.traceCount, 1); sync();
+    std::vector<StepRecord> tmp((size_t)m);
+    if (m) { download(tmp.data(), a_.trace, (size_t)m); sync(); }
+    for (int64_t i = 0; i < m && i < cap; ++i) std::memcpy(out + 5 * i, &tmp[(size_t)i], 20);
+    HIP_OK(hipMemsetAsync(a_.traceCount, 0, 4, stream_)); sync();
+    return m;
+  }
+
+  // ---- offsets / scale
+  void offset_from_host(const double* off) {
+    upload(a_.offNew, off, (size_t)n_);
+    hipLaunchKernelGGL(k_param_mean, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, 0, 0, 0, 1, a_.offNew); ++launches_;
+  }
+  void offset_from_params(const double* beta, const double* b, int fixed, int random, int addUser) {
+    push_params(beta, b);
+    hipLaunchKernelGGL(k_param_mean, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, fixed, random, addUser, 0, a_.offNew); ++launches_;
+  }
+  void param_mean_to_host(const double* beta, const double* b, double* out) {
+    push_params(beta, b);
+    hipLaunchKernelGGL(k_param_mean, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, 1, 1, 0, 0, s_.e); ++launches_;
+    download(out, s_.e, (size_t)n_); sync();
+  }
+  void set_sigma(double s) { hipLaunchKernelGGL(k_set_sigma, dim3(1), dim3(1), 0, stream_, a_, s); ++launches_; }
+  void rescale(bool update) {
+    hipLaunchKernelGGL(k_scale, dim3(1), dim3(BLOCK), 0, stream_, a_, s_, update ? 1 : 0, gridN_); ++launches_;
+    hipLaunchKernelGGL(k_rescale, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, update ? 1 : 0); ++launches_;
+    std::swap(a_.off, a_.offNew);
+  }
+
+  // ---- trees
+  void assign_leaves_and_residual() { hipLaunchKernelGGL(k_assign_leaves, dim3(gridN_), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+  void sweep(int thin) {
+    for (int k = 0; k < thin; ++k) {
+      hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), useLds_ ? ldsControl_ : 0, stream_, a_, -1, 0, useLds_); ++launches_;
+      for (int t = 0; t < T_; ++t) {
+        hipLaunchKernelGGL(k_stats, dim3(a_.grid), dim3(BLOCK), ldsStats_, stream_, a_, t); ++launches_;
+        hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), useLds_ ? ldsControl_ : 0, stream_, a_, t, t + 1 < T_ ? t + 1 : -1, useLds_); ++launches_;
+        hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, t); ++launches_;
+      }
+    }
+  }
+  void test_fits(double* out) {
+    int g = (int)std::min<int64_t>(GRID_MAX, std::max<int64_t>(1, (nTest_ + BLOCK - 1) / BLOCK));
+    hipLaunchKernelGGL(k_test_fits, dim3(g), dim3(BLOCK), 0, stream_, a_, testOut_); ++launches_;
+    download(out, testOut_, (size_t)nTest_); sync();
+  }
+
+  // ---- Stan inputs
+  void stan_inputs(int mode, bool wantTrain, double* cX, double* cZ, double* s0, double* trainOut) {
+    reduce_pipeline(mode, wantTrain ? 1 : 0, 0);
+    fetch_out(cX, cZ, s0);
+    if (wantTrain && trainOut) { download(trainOut, s_.train, (size_t)n_); sync(); }
+  }
+  double leapfrog_sums(const double* beta, const double* b, double* gX, double* gZ) {
+    push_params(beta, b);
+    reduce_pipeline(0, 0, 1);
+    double ss; fetch_out(gX, gZ, &ss);
+    return ss;
+  }
+
+  // timing hook for bench.py: events on the stream the kernels are launched on
+  hipStream_t stream() const { return stream_; }
+  const BartArrays& arrays() const { return a_; }
+  void sync() { HIP_OK(hipStreamSynchronize(stream_)); }
+
+ private:
+  template <class T> T* alloc(size_t count) { void* p = nullptr; HIP_OK(hipMalloc(&p, std::max<size_t>(16, count * sizeof(T)))); allocs_.push_back(p); return (T*)p; }
+  template <class T> T* zalloc(size_t count) { T* p = alloc<T>(count); HIP_OK(hipMemsetAsync(p, 0, std::max<size_t>(16, count * sizeof(T)), stream_)); return p; }
+  template <class T> void upload(T* dst, const T* src, size_t count) { if (count) HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, stream_)); }
+  template <class T> void download(T* dst, const T* src, size_t count) { if (count) HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, stream_)); }
+
+  void push_params(const double* beta, const double* b) {
+    double* h = pinned_ + (1 + K_ + q_);
+    // the previous async copy out of this staging area must have completed before we overwrite it
+    sync();
+    for (int k = 0; k < K_; ++k) h[k] = beta[k];
+    for (int j = 0; j < q_; ++j) h[K_ + j] = b[j];
+    if (K_ + q_) HIP_OK(hipMemcpyAsync(s_.params, h, (size_t)(K_ + q_) * 8, hipMemcpyHostToDevice, stream_));
+  }
+  void reduce_pipeline(int mode, int wantTrain, int direct) {
+    hipLaunchKernelGGL(k_stan_inputs, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, mode, wantTrain, direct); ++launches_;
+    for (int k0 = 3; k0 < K_; k0 += 4) { hipLaunchKernelGGL(k_xt_e, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, k0, direct); ++launches_; }
+    if (s_.numChunks) { hipLaunchKernelGGL(k_zt_chunks, dim3(s_.numChunks), dim3(BLOCK), 0, stream_, s_, direct); ++launches_; }
+    hipLaunchKernelGGL(k_stan_finalize, dim3(1), dim3(BLOCK), 0, stream_, a_, s_, gridN_); ++launches_;
+  }
+  void fetch_out(double* cX, double* cZ, double* s0) {
+    HIP_OK(hipMemcpyAsync(pinned_, s_.out, (size_t)(1 + K_ + q_) * 8, hipMemcpyDeviceToHost, stream_));
+    sync();
+    *s0 = pinned_[0];
+    for (int k = 0; k < K_; ++k) cX[k] = pinned_[1 + k];
+    for (int j = 0; j < q_; ++j) cZ[j] = pinned_[1 + K_ + j];
+  }
+  void build_csc(const DevInit& d) {
+    // column-major copy of Z with ascending rows inside a column, cut into fixed chunks of <= CHUNK entries
+    const int CHUNK = 4096;
+    std::vector<int64_t> colCount((size_t)q_ + 1, 0);
+    for (int64_t e = 0; e < d.nnz; ++e) ++colCount[(size_t)d.v[e] + 1];
+    for (int j = 0; j < q_; ++j) colCount[(size_t)j + 1] += colCount[(size_t)j];
+    std::vector<int32_t> row((size_t)d.nnz); std::vector<double> val((size_t)d.nnz);
+    std::vector<int64_t> fill(colCount.begin(), colCount.end() - 1);
+    for (int64_t i = 0; i < n_; ++i) for (int e = d.u[i]; e < d.u[i + 1]; ++e) { int64_t pos = fill[(size_t)d.v[e]]++; row[(size_t)pos] = (int32_t)i; val[(size_t)pos] = d.w[e]; }
+    std::vector<int32_t> chunkCol, chunkLen, colChunkPtr((size_t)q_ + 1, 0); std::vector<int64_t> chunkStart;
+    for (int j = 0; j < q_; ++j) {
+      colChunkPtr[(size_t)j] = (int32_t)chunkCol.size();
+      for (int64_t st = colCount[(size_t)j]; st < colCount[(size_t)j + 1]; st += CHUNK) {
+        chunkCol.push_back(j); chunkStart.push_back(st); chunkLen.push_back((int32_t)std::min<int64_t>(CHUNK, colCount[(size_t)j + 1] - st));
+      }
+    }
+    colChunkPtr[(size_t)q_] = (int32_t)chunkCol.size();
+    StanArrays& s = s_;
+    s.numChunks = (int32_t)chunkCol.size();
+    int32_t* dr = alloc<int32_t>(row.size()); upload(dr, row.data(), row.size()); s.cscRow = dr;
+    double* dv = alloc<double>(val.size()); upload(dv, val.data(), val.size()); s.cscVal = dv;
+    int32_t* cc = alloc<int32_t>(chunkCol.size()); upload(cc, chunkCol.data(), chunkCol.size()); s.chunkCol = cc;
+    int64_t* cs = alloc<int64_t>(chunkStart.size()); upload(cs, chunkStart.data(), chunkStart.size()); s.chunkStart = cs;
+    int32_t* cl = alloc<int32_t>(chunkLen.size()); upload(cl, chunkLen.data(), chunkLen.size()); s.chunkLen = cl;
+    int32_t* cp = alloc<int32_t>(colChunkPtr.size()); upload(cp, colChunkPtr.data(), colChunkPtr.size()); s.colChunkPtr = cp;
+    s.chunkPart = zalloc<double>((size_t)std::max(1, s.numChunks));
+    HIP_OK(hipStreamSynchronize(stream_));   // host vectors go out of scope
+  }
+
+  int device_ = 0; hipStream_t stream_ = nullptr; hipEvent_t evStart_ = nullptr, evStop_ = nullptr;
+  int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1, useLds_ = 1;
+  size_t ldsStats_ = 0, ldsApply_ = 0, ldsControl_ = 0;
+  BartArrays a_; StanArrays s_;
+  std::vector<void*> allocs_;
+  double* pinned_ = nullptr; double* testOut_ = nullptr;
+  int64_t launches_ = 0;
+};
+
+}  // namespace s4b
+
+#define S4B_DEV s4b::DevHip
+#include "c_api.inc"

@@ -1,0 +1,139 @@
+// R-compatible random stream for the BART block, usable from device code.
+//
+// The reference's BART block consumes R's global generator (reference src/init.cpp:259,750
+// GetRNGstate; dbarts draws unif_rand/norm_rand/exp_rand from it in single-chain mode).  On the
+// MI355X path the Mersenne-Twister state lives in device memory and one lane of the per-tree
+// `decide` kernel advances it, so accept/reject decisions never leave the GPU.  The same code
+// compiles for the host (tree initialisation at create time, CPU unit tests of the host logic).
+#ifndef S4B_RRNG_HD_HPP
+#define S4B_RRNG_HD_HPP
+
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define S4B_HD __host__ __device__
+#else
+#define S4B_HD
+#endif
+
+namespace s4b {
+
+struct MTState {
+  uint32_t mt[624];
+  int32_t mti;
+  int32_t pad;
+};
+
+S4B_HD inline void mt_regenerate(MTState* s) {
+  uint32_t* mt = s->mt;
+  for (int k = 0; k < 624; ++k) {
+    uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+    uint32_t v = mt[(k + 397) % 624] ^ (y >> 1);
+    if (y & 1u) v ^= 0x9908b0dfu;
+    mt[k] = v;
+  }
+  s->mti = 0;
+}
+
+S4B_HD inline uint32_t mt_next(MTState* s) {
+  if (s->mti >= 624) mt_regenerate(s);
+  uint32_t y = s->mt[s->mti++];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+S4B_HD inline double r_unif(MTState* s) {
+  const double half_ulp = 0.5 * 2.328306437080797e-10;
+  double v = (double)mt_next(s) * 2.3283064365386963e-10;
+  if (v <= 0.0) return half_ulp;
+  if (1.0 - v <= 0.0) return 1.0 - half_ulp;
+  return v;
+}
+
+// quantile of N(0,1): AS241 (PPND16), as R's qnorm5
+S4B_HD inline double r_qnorm(double p) {
+  double q = p - 0.5;
+  if (fabs(q) <= 0.425) {
+    double r = 0.180625 - q * q;
+    double num = 2509.0809287301226727;
+    num = num * r + 33430.575583588128105; num = num * r + 67265.770927008700853;
+    num = num * r + 45921.953931549871457; num = num * r + 13731.693765509461125;
+    num = num * r + 1971.5909503065514427; num = num * r + 133.14166789178437745;
+    num = num * r + 3.387132872796366608;
+    double den = 5226.495278852545925;
+    den = den * r + 28729.085735721942674; den = den * r + 39307.89580009271061;
+    den = den * r + 21213.794301586595867; den = den * r + 5394.1960214247511077;
+    den = den * r + 687.1870074920579083; den = den * r + 42.313330701600911252;
+    den = den * r + 1.0;
+    return q * num / den;
+  }
+  double r = q < 0.0 ? p : 1.0 - p;
+  r = sqrt(-log(r));
+  double val;
+  if (r <= 5.0) {
+    r -= 1.6;
+    double num = 7.7454501427834140764e-4;
+    num = num * r + 0.0227238449892691845833; num = num * r + 0.24178072517745061177;
+    num = num * r + 1.27045825245236838258; num = num * r + 3.64784832476320460504;
+    num = num * r + 5.7694972214606914055; num = num * r + 4.6303378461565452959;
+    num = num * r + 1.42343711074968357734;
+    double den = 1.05075007164441684324e-9;
+    den = den * r + 5.475938084995344946e-4; den = den * r + 0.0151986665636164571966;
+    den = den * r + 0.14810397642748007459; den = den * r + 0.68976733498510000455;
+    den = den * r + 1.6763848301838038494; den = den * r + 2.05319162663775882187;
+    den = den * r + 1.0;
+    val = num / den;
+  } else {
+    r -= 5.0;
+    double num = 2.01033439929228813265e-7;
+    num = num * r + 2.71155556874348757815e-5; num = num * r + 0.0012426609473880784386;
+    num = num * r + 0.026532189526576123093; num = num * r + 0.29656057182850489123;
+    num = num * r + 1.7848265399172913358; num = num * r + 5.4637849111641143699;
+    num = num * r + 6.6579046435011037772;
+    double den = 2.04426310338993978564e-15;
+    den = den * r + 1.4215117583164458887e-7; den = den * r + 1.8463183175100546818e-5;
+    den = den * r + 7.868691311456132591e-4; den = den * r + 0.0148753612908506148525;
+    den = den * r + 0.13692988092273580531; den = den * r + 0.59983220655588793769;
+    den = den * r + 1.0;
+    val = num / den;
+  }
+  return q < 0.0 ? -val : val;
+}
+
+// norm_rand() with N01_kind = INVERSION
+S4B_HD inline double r_norm(MTState* s) {
+  const double BIG = 134217728.0;
+  double u = r_unif(s);
+  u = (double)(int)(BIG * u) + r_unif(s);
+  return r_qnorm(u / BIG);
+}
+
+// exp_rand() (Ahrens & Dieter 1972 as in R's sexp.c)
+S4B_HD inline double r_exp(MTState* s) {
+  const double q[16] = {0.6931471805599453, 0.9333736875190459, 0.9888777961838675, 0.9984589039328340,
+                        0.9998292811061389, 0.9999833164100727, 0.9999985691438767, 0.9999998906925558,
+                        0.9999999924734159, 0.9999999995283275, 0.9999999999728814, 0.9999999999985598,
+                        0.9999999999999289, 0.9999999999999968, 0.9999999999999999, 1.0000000000000000};
+  double a = 0.0;
+  double u = r_unif(s);
+  while (u <= 0.0 || u >= 1.0) u = r_unif(s);
+  for (;;) { u += u; if (u > 1.0) break; a += q[0]; }
+  u -= 1.0;
+  if (u <= q[0]) return a + u;
+  int i = 0;
+  double ustar = r_unif(s), umin = ustar;
+  do { ustar = r_unif(s); if (umin > ustar) umin = ustar; ++i; } while (u > q[i]);
+  return a + umin * q[0];
+}
+
+// uniform integer in [lo, hi) the way dbarts' ext_rng does it: lo + (int64)(u * range)
+S4B_HD inline int r_unif_int(MTState* s, int lo, int hi_excl) {
+  return lo + (int)(r_unif(s) * (double)(hi_excl - lo));
+}
+
+}  // namespace s4b
+#endif

@@ -1,0 +1,387 @@
+// Host orchestration of one chain of the blocked Gibbs sampler on top of a device layer.
+//
+// Mirrors the reference's C++ driver — `Sampler` (reference src/init.cpp:124-173), createSampler
+// (:190-310) and run (:678-965, loop body :752-917) — with the two blocks re-targeted:
+//   * BART block: device-resident (DevLayer::sweep); nothing O(N) crosses PCIe inside the loop.
+//   * Stan block: NUTS control flow on the host (stan_host.hpp), O(N) sums on the device, by default
+//     folded into sufficient statistics once per Gibbs iteration.
+// `Dev` is the device layer.  The product instantiates it with the HIP layer (dev_hip.hip); a CPU
+// emulation of the same interface exists only under tests/emul to exercise this file without a GPU.
+#ifndef S4B_SAMPLER_CORE_HPP
+#define S4B_SAMPLER_CORE_HPP
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/stan4bart_amd.h"
+#include "dev_common.hpp"
+#include "stan_host.hpp"
+
+namespace s4b {
+
+enum { OFFSET_DEFAULT = 0, OFFSET_FIXEF, OFFSET_RANEF, OFFSET_BART, OFFSET_PARAMETRIC };
+
+// everything the device layer needs at creation (host pointers, valid during init() only)
+struct DevInit {
+  int64_t n = 0, nTest = 0; int32_t P = 0, T = 0, nc = 256, device = 0;
+  const uint16_t* xbin = nullptr;      // [P][n]
+  const uint16_t* xbinTest = nullptr;  // [P][nTest]
+  const int32_t* numCuts = nullptr;
+  const double* y = nullptr;
+  const double* userOffset = nullptr;
+  ModelView model;
+  int32_t K = 0, q = 0;
+  const double* X = nullptr;           // n x K column-major
+  const double* w = nullptr; const int32_t* v = nullptr; const int32_t* u = nullptr; int64_t nnz = 0;
+  int32_t traceCap = 0;
+};
+
+template <class Dev>
+class SamplerCore {
+ public:
+  SamplerCore(const s4b_bart_control* bc, const s4b_bart_data* bd, const s4b_stan_data* sd, const s4b_stan_control* sc,
+              const s4b_common_control* cc, const uint32_t* rstate) {
+    if (!bc || !bd || !sd || !sc || !cc || !rstate) throw std::invalid_argument("create: NULL argument");
+    if (bd->n != sd->N) throw std::invalid_argument("bart data n != stan data N");
+    if (bd->n < 1 || bd->p < 1) throw std::invalid_argument("bart data must have n >= 1, p >= 1");
+    if (bc->n_trees < 1) throw std::invalid_argument("n_trees must be >= 1");
+    if (!(cc->sigma_init > 0)) throw std::invalid_argument("sigma_init must be > 0");
+    if (cc->is_binary || sd->is_binary) throw std::invalid_argument("binary (probit) responses are not supported by the device path yet");
+    if (sd->has_weights) throw std::invalid_argument("weights are not supported by the device path yet");
+    if (sd->has_intercept) throw std::invalid_argument("has_intercept = 1 is not supported (BART supplies the intercept)");
+    if (sd->prior_dist < 0 || sd->prior_dist > 2) throw std::invalid_argument("prior_dist must be 0, 1 or 2");
+    n_ = (size_t)bd->n; P_ = bd->p; T_ = bc->n_trees; nTest_ = (size_t)bd->n_test;
+    warmup_ = cc->warmup; verbose_ = cc->verbose; keepFits_ = cc->keep_fits != 0; offsetType_ = cc->offset_type;
+    callback_ = cc->callback; callbackUser_ = cc->callback_user;
+    thin_ = bc->n_thin > 0 ? bc->n_thin : 1;
+    nc_ = bc->node_capacity > 0 ? bc->node_capacity : 256;
+    if (nc_ < 3 || nc_ > 32000) throw std::invalid_argument("node_capacity must be in [3, 32000]");
+    if (cc->offset) { userOffset_.assign(cc->offset, cc->offset + n_); hasUserOffset_ = true; }
+    rng_.mti = (int32_t)rstate[0];
+    std::memcpy(rng_.mt, rstate + 1, 624 * sizeof(uint32_t));
+
+    // ---- Stan spec + host copies of the design (the reference copies them too: stan_sampler.cpp:197-249)
+    StanSpec sp;
+    sp.N = sd->N; sp.K = sd->K; sp.q = sd->q; sp.t = sd->t; sp.len_theta_L = sd->len_theta_L;
+    sp.is_binary = 0; sp.prior_dist = sd->prior_dist; sp.prior_dist_for_aux = sd->prior_dist_for_aux;
+    if (sd->K) { sp.prior_scale.assign(sd->prior_scale, sd->prior_scale + sd->K); sp.prior_mean.assign(sd->prior_mean, sd->prior_mean + sd->K);
+                 sp.prior_df.assign(sd->prior_df, sd->prior_df + sd->K); }
+    sp.prior_scale_for_aux = sd->prior_scale_for_aux; sp.prior_mean_for_aux = sd->prior_mean_for_aux; sp.prior_df_for_aux = sd->prior_df_for_aux;
+    if (sd->t) { sp.p.assign(sd->p, sd->p + sd->t); sp.l.assign(sd->l, sd->l + sd->t); sp.shape.assign(sd->shape, sd->shape + sd->t);
+                 sp.scale.assign(sd->scale, sd->scale + sd->t); }
+    if (sd->len_concentration) sp.concentration.assign(sd->concentration, sd->concentration + sd->len_concentration);
+    if (sd->len_regularization) sp.regularization.assign(sd->regularization, sd->regularization + sd->len_regularization);
+    {
+      int qq = 0; for (int i = 0; i < sd->t; ++i) qq += sd->p[i] * sd->l[i];
+      if (qq != sd->q) throw std::invalid_argument("q != sum(p * l)");
+      for (int64_t e = 0; e < sd->num_non_zero; ++e) if (sd->v[e] < 0 || sd->v[e] >= sd->q) throw std::invalid_argument("CSR column index out of range");
+    }
+    model_.reset(new HostModel(sp));
+    K_ = sd->K; q_ = sd->q; hmcMode_ = sc->hmc_mode;
+    cX_.assign((size_t)K_, 0.0); cZ_.assign((size_t)q_, 0.0);
+
+    // ---- BART data: cut points + binning on the host (one-off), model constants
+    numCuts_.assign(bd->n_cuts, bd->n_cuts + P_);
+    for (int j = 0; j < P_; ++j) if (numCuts_[(size_t)j] < 0 || numCuts_[(size_t)j] > 65534) throw std::invalid_argument("n_cuts must be in [0, 65534]");
+    make_cuts(bd->x);
+    std::vector<uint16_t> xbin((size_t)P_ * n_), xbinTest((size_t)P_ * nTest_);
+    bin_matrix(bd->x, n_, xbin);
+    if (nTest_) bin_matrix(bd->x_test, nTest_, xbinTest);
+
+    DevInit di;
+    di.n = (int64_t)n_; di.nTest = (int64_t)nTest_; di.P = P_; di.T = T_; di.nc = nc_; di.device = cc->device;
+    di.xbin = xbin.data(); di.xbinTest = nTest_ ? xbinTest.data() : nullptr; di.numCuts = numCuts_.data();
+    di.y = sd->y; di.userOffset = hasUserOffset_ ? userOffset_.data() : nullptr;
+    di.model.P = P_; di.model.Pvalid = 0;
+    for (int j = 0; j < P_; ++j) if (numCuts_[(size_t)j] > 0) ++di.model.Pvalid;
+    if (di.model.Pvalid == 0) throw std::invalid_argument("no predictor has a cut point");
+    di.model.numCuts = nullptr;
+    di.model.base = bc->base; di.model.power = bc->power;
+    di.model.pBD = bc->birth_or_death_prob; di.model.pSwap = bc->swap_prob; di.model.pChange = bc->change_prob; di.model.pBirth = bc->birth_prob;
+    { double sd_mu = bc->node_scale / (bc->k * std::sqrt((double)T_)); di.model.leafPrec = 1.0 / (sd_mu * sd_mu); }
+    di.K = K_; di.q = q_; di.X = sd->X; di.w = sd->w; di.v = sd->v; di.u = sd->u; di.nnz = sd->num_non_zero;
+    di.traceCap = 1 << 16;
+    hostModelView_ = di.model; hostModelView_.numCuts = numCuts_.data();
+    dev_.init(di);
+
+    // ---- Stan sampler: init + init_stepsize run against offset_ = 0 and the raw y (reference
+    //      interruptable_sampler.hpp:150,175-176 happen before any BART fit exists)
+    if (hmcMode_ == 0) build_gram(sd);
+    dev_.stan_inputs(/*mode raw y*/ 0, false, cX_.data(), cZ_.data(), &s0_, nullptr);
+    model_->lik = [this](const double* beta, const double* b, double* gX, double* gZ) { return likelihood(beta, b, gX, gZ); };
+    NutsControl nc;
+    nc.seed = sc->seed; nc.init_r = sc->init_r; nc.skip = sc->skip;
+    if (nc.skip <= 0) { nc.skip = (2000 - warmup_) / 1000; if (nc.skip < 1) nc.skip = 1; }
+    nc.gamma = sc->adapt_gamma; nc.delta = sc->adapt_delta; nc.kappa = sc->adapt_kappa; nc.t0 = sc->adapt_t0;
+    nc.init_buffer = sc->adapt_init_buffer; nc.term_buffer = sc->adapt_term_buffer; nc.window = sc->adapt_window;
+    nc.stepsize = sc->stepsize; nc.jitter = sc->stepsize_jitter; nc.max_depth = sc->max_treedepth;
+    nuts_.reset(new Nuts(*model_, nc, 1, warmup_));
+    row_.assign((size_t)(7 + model_->sp.n_constrained), 0.0);
+
+    // ---- BART init (reference src/init.cpp:236-273)
+    std::vector<double> bartOffset(n_, 0.0);
+    const double* boi = cc->bart_offset_init;
+    if (hasUserOffset_) {
+      if (offsetType_ != OFFSET_BART) {
+        bartOffset = userOffset_;
+        if (boi && offsetType_ == OFFSET_DEFAULT) for (size_t i = 0; i < n_; ++i) bartOffset[i] += boi[i];
+      } else if (boi) bartOffset.assign(boi, boi + n_);
+    } else if (boi) bartOffset.assign(boi, boi + n_);
+    dev_.offset_from_host(bartOffset.data());
+    dev_.rescale(true);
+    dev_.set_sigma(cc->sigma_init);
+    sigma_ = cc->sigma_init;
+    sample_trees_from_prior();
+    dev_.sweep(thin_);
+    treeUpdates_ += (long)T_ * thin_;
+    dev_.stan_inputs(stan_mode(), false, cX_.data(), cZ_.data(), &s0_, nullptr);
+    check_device();
+  }
+
+  // stan4bart_run (reference src/init.cpp:678-965)
+  void run(int numIter, bool isWarmup, int resultsType, s4b_results* out) {
+    if (numIter < 1) throw std::invalid_argument("num_iter must be >= 1");
+    const bool doStan = resultsType == 0 || resultsType == 2, doBart = resultsType == 0 || resultsType == 1;
+    const int numPars = (int)row_.size();
+    size_t slot = 0;
+    std::vector<double> train, test;
+    const bool wantTrain = (out && out->bart_train) || callback_;
+    if (wantTrain) train.resize(n_);
+    if (nTest_) test.resize(nTest_);
+    for (int iter = 0; iter < numIter; ++iter) {
+      if (doStan) {
+        nuts_->run(row_.data());
+        const double* cons = row_.data() + 7;
+        const double* beta = cons + model_->sp.beta_pos();
+        const double* b = cons + model_->sp.b_pos();
+        if (!hasUserOffset_) dev_.offset_from_params(beta, b, 1, 1, 0);
+        else switch (offsetType_) {
+          case OFFSET_DEFAULT: dev_.offset_from_params(beta, b, 1, 1, 1); break;
+          case OFFSET_BART: dev_.offset_from_params(beta, b, 1, 1, 0); break;
+          case OFFSET_RANEF: dev_.offset_from_params(beta, b, 1, 0, 1); break;
+          case OFFSET_FIXEF: dev_.offset_from_params(beta, b, 0, 1, 1); break;
+          case OFFSET_PARAMETRIC: dev_.offset_from_params(beta, b, 0, 0, 1); break;
+        }
+        sigma_ = cons[model_->sp.aux_pos()];
+        dev_.set_sigma(sigma_);
+        if (out && out->stan) std::memcpy(out->stan + slot * (size_t)numPars, row_.data(), (size_t)numPars * sizeof(double));
+        int update_scale_mod = 1 << (8 * iter / numIter);
+        dev_.rescale(isWarmup && iter % update_scale_mod == 0);
+      }
+      if (doBart) {
+        dev_.sweep(thin_);
+        treeUpdates_ += (long)T_ * thin_;
+        dev_.stan_inputs(stan_mode(), wantTrain, cX_.data(), cZ_.data(), &s0_, wantTrain ? train.data() : nullptr);
+        if (nTest_ && ((out && out->bart_test) || callback_)) dev_.test_fits(test.data());
+        if (out) {
+          if (out->bart_sigma) out->bart_sigma[slot] = sigma_;
+          if (out->bart_train) std::memcpy(out->bart_train + slot * n_, train.data(), n_ * sizeof(double));
+          if (out->bart_test && nTest_) std::memcpy(out->bart_test + slot * nTest_, test.data(), nTest_ * sizeof(double));
+          if (out->bart_varcount) var_counts(out->bart_varcount + slot * (size_t)P_);
+        }
+        if (callback_) callback_(callbackUser_, train.data(), nTest_ ? test.data() : nullptr, row_.data(), numPars);
+      }
+      if (keepFits_) ++slot;
+    }
+    check_device();
+  }
+
+  void disengage_adaptation() { nuts_->disengage(); }
+
+  void parametric_mean(double* out) {
+    const double* cons = row_.data() + 7;
+    dev_.param_mean_to_host(cons + model_->sp.beta_pos(), cons + model_->sp.b_pos(), out);
+  }
+  void data_range(double out[2]) { ScaleState s; dev_.get_scale(s); out[0] = s.min; out[1] = s.max; }
+  void get_rng(uint32_t* st) { dev_.download_rng(rng_); st[0] = (uint32_t)rng_.mti; std::memcpy(st + 1, rng_.mt, 624 * 4); }
+  void set_rng(const uint32_t* st) { rng_.mti = (int32_t)st[0]; std::memcpy(rng_.mt, st + 1, 624 * 4); dev_.upload_rng(rng_); }
+  void dims(int64_t d[5]) { d[0] = (int64_t)row_.size(); d[1] = (int64_t)n_; d[2] = (int64_t)nTest_; d[3] = P_; d[4] = T_; }
+  std::string par_names() const {
+    const StanSpec& m = model_->sp;
+    std::string o = "lp__\naccept_stat__\nstepsize__\ntreedepth__\nn_leapfrog__\ndivergent__\nenergy__";
+    auto add = [&](const char* base, int cnt) { for (int i = 1; i <= cnt; ++i) o += "\n" + std::string(base) + "." + std::to_string(i); };
+    add("z_beta", m.K); add("z_b", m.q); add("z_T", m.len_z_T); add("rho", m.len_rho); add("zeta", m.len_conc); add("tau", m.t);
+    add("aux_unscaled", 1); add("aux", 1);
+    add("beta", m.K); add("b", m.q); add("theta_L", m.len_theta_L);
+    return o;
+  }
+  void print_summary() const {
+    std::printf("stan4bart_amd sampler: n = %zu, p = %d, trees = %d, node capacity = %d, unconstrained stan params = %d, hmc mode = %s\n",
+                n_, P_, T_, nc_, model_->sp.D, hmcMode_ == 0 ? "sufficient statistics" : "per-leapfrog kernels");
+  }
+
+  // flattened live trees, preorder (stan4bart_getTrees layout; reference src/init.cpp:583-665)
+  int64_t get_trees(int64_t cap, int32_t* tree, int32_t* n_obs, int32_t* var, int32_t* split, double* value) {
+    HostTrees h; download_trees(h);
+    int64_t cnt = 0;
+    for (int t = 0; t < T_; ++t) {
+      TreeView tv = h.view(t, nc_);
+      std::vector<int32_t> ncount((size_t)nc_, 0);
+      { int nd, k; Walker w(tv, 0);   // post-order: counts of internal nodes
+        while (w.next(nd, k)) { if (k == 0) ncount[(size_t)nd] = h.cnt[(size_t)t * nc_ + nd]; else if (k == 2) ncount[(size_t)nd] = ncount[(size_t)tv.left[nd]] + ncount[(size_t)tv.right[nd]]; } }
+      int nd, k; Walker w(tv, 0);
+      while (w.next(nd, k)) {
+        if (k == 2) continue;
+        if (cnt < cap && tree) {
+          tree[cnt] = t; n_obs[cnt] = ncount[(size_t)nd];
+          if (k == 1) { var[cnt] = tv.var[nd]; split[cnt] = tv.cut[nd]; value[cnt] = cuts_[(size_t)tv.var[nd]][(size_t)tv.cut[nd]]; }
+          else { var[cnt] = -1; split[cnt] = -1; value[cnt] = h.mu[(size_t)t * nc_ + nd]; }
+        }
+        ++cnt;
+      }
+    }
+    return cnt;
+  }
+  void set_trace(bool on) { dev_.set_trace(on); }
+  int64_t get_trace(int64_t cap, int32_t* out) { return dev_.get_trace(cap, out); }
+  void leaf_assignment(int t, int32_t* out) {
+    if (t < 0 || t >= T_) throw std::invalid_argument("tree index out of range");
+    HostTrees h; download_trees(h);
+    TreeView tv = h.view(t, nc_);
+    std::vector<int16_t> list((size_t)nc_); std::vector<int32_t> rank((size_t)nc_, -1);
+    int nl = tv_list_leaves(tv, 0, list.data());
+    for (int i = 0; i < nl; ++i) rank[(size_t)list[(size_t)i]] = i;
+    std::vector<uint16_t> leaf(n_);
+    dev_.download_leaf_plane(t, leaf.data());
+    for (size_t i = 0; i < n_; ++i) out[i] = rank[leaf[i]];
+  }
+  void counters(int64_t out[3]) { out[0] = model_->gradEvals; out[1] = treeUpdates_; out[2] = dev_.launches(); }
+  Dev& dev() { return dev_; }
+
+ private:
+  struct HostTrees {
+    std::vector<int16_t> var, left, right, parent; std::vector<uint16_t> cut; std::vector<double> mu; std::vector<int32_t> cnt, hwm;
+    TreeView view(int t, int nc) { TreeView v; size_t o = (size_t)t * nc; v.var = var.data() + o; v.cut = cut.data() + o; v.left = left.data() + o;
+                                   v.right = right.data() + o; v.parent = parent.data() + o; v.nc = nc; return v; }
+    void alloc(int T, int nc) { size_t m = (size_t)T * nc; var.assign(m, NODE_FREE); left.assign(m, -1); right.assign(m, -1); parent.assign(m, -1);
+                                cut.assign(m, 0); mu.assign(m, 0.0); cnt.assign(m, 0); hwm.assign((size_t)T, 1); }
+  };
+  void download_trees(HostTrees& h) { h.alloc(T_, nc_); dev_.download_trees(h.var.data(), h.cut.data(), h.left.data(), h.right.data(), h.parent.data(), h.mu.data(), h.cnt.data(), h.hwm.data()); }
+
+  int stan_mode() const {   // how the Stan offset is formed from the BART fit (reference src/init.cpp:831-839)
+    if (hasUserOffset_ && offsetType_ == OFFSET_BART) return 2;      // stanOffset = userOffset
+    if (hasUserOffset_ && offsetType_ == OFFSET_DEFAULT) return 3;   // bart fit + userOffset
+    return 1;                                                        // bart fit
+  }
+
+  void make_cuts(const double* x) {   // uniform cut points between the column extremes
+    cuts_.resize((size_t)P_);
+    for (int j = 0; j < P_; ++j) {
+      const double* col = x + (size_t)j * n_;
+      double mn = col[0], mx = col[0];
+      for (size_t i = 1; i < n_; ++i) { if (col[i] < mn) mn = col[i]; if (col[i] > mx) mx = col[i]; }
+      int m = numCuts_[(size_t)j];
+      cuts_[(size_t)j].resize((size_t)m);
+      for (int c = 0; c < m; ++c) cuts_[(size_t)j][(size_t)c] = mn + (double)(c + 1) * (mx - mn) / (double)(m + 1);
+    }
+  }
+  void bin_matrix(const double* x, size_t m, std::vector<uint16_t>& out) const {
+    auto work = [&](int j0, int j1) {
+      for (int j = j0; j < j1; ++j) {
+        const std::vector<double>& c = cuts_[(size_t)j];
+        const double* col = x + (size_t)j * m; uint16_t* o = out.data() + (size_t)j * m;
+        for (size_t i = 0; i < m; ++i) o[i] = (uint16_t)(std::lower_bound(c.begin(), c.end(), col[i]) - c.begin());   // #cuts strictly below x
+      }
+    };
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), (unsigned)P_);
+    if ((size_t)P_ * m < (1u << 22)) nt = 1;
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; ++k) th.emplace_back(work, (int)((size_t)P_ * k / nt), (int)((size_t)P_ * (k + 1) / nt));
+    for (auto& t : th) t.join();
+  }
+
+  // dbarts sampleTreesFromPrior (reference src/init.cpp:261): structure by recursive growth, leaf values from the prior
+  void grow(TreeView& tv, int& hwm, int node) {
+    double pg = tv_growth(tv, hostModelView_, node);
+    if (pg <= 0.0) return;
+    if (!(r_unif(&rng_) < pg)) return;
+    int v = tv_draw_var(tv, hostModelView_, node, &rng_);
+    int lo, hi; tv_interval(tv, hostModelView_, node, v, lo, hi);
+    int s = r_unif_int(&rng_, lo, hi + 1);
+    int L = tv_alloc(tv, hwm); if (L < 0) throw std::runtime_error("node capacity exceeded while sampling trees from the prior");
+    tv.var[L] = NODE_LEAF;
+    int R = tv_alloc(tv, hwm); if (R < 0) throw std::runtime_error("node capacity exceeded while sampling trees from the prior");
+    tv.var[node] = (int16_t)v; tv.cut[node] = (uint16_t)s; tv.left[node] = (int16_t)L; tv.right[node] = (int16_t)R;
+    tv.var[L] = NODE_LEAF; tv.parent[L] = (int16_t)node; tv.left[L] = tv.right[L] = -1;
+    tv.var[R] = NODE_LEAF; tv.parent[R] = (int16_t)node; tv.left[R] = tv.right[R] = -1;
+    grow(tv, hwm, L); grow(tv, hwm, R);
+  }
+  void sample_trees_from_prior() {
+    HostTrees h; h.alloc(T_, nc_);
+    std::vector<int16_t> list((size_t)nc_);
+    for (int t = 0; t < T_; ++t) {
+      TreeView tv = h.view(t, nc_);
+      tv.var[0] = NODE_LEAF; tv.parent[0] = -1;
+      int hwm = 1;
+      grow(tv, hwm, 0);
+      int nl = tv_list_leaves(tv, 0, list.data());
+      for (int i = 0; i < nl; ++i) h.mu[(size_t)t * nc_ + list[(size_t)i]] = r_norm(&rng_) / std::sqrt(hostModelView_.leafPrec);
+      h.hwm[(size_t)t] = hwm;
+    }
+    dev_.upload_trees(h.var.data(), h.cut.data(), h.left.data(), h.right.data(), h.parent.data(), h.mu.data(), h.hwm.data());
+    dev_.upload_rng(rng_);
+    dev_.assign_leaves_and_residual();
+  }
+
+  void var_counts(int32_t* out) {
+    HostTrees h; download_trees(h);
+    for (int j = 0; j < P_; ++j) out[j] = 0;
+    for (int t = 0; t < T_; ++t) { TreeView tv = h.view(t, nc_); int nd, k; Walker w(tv, 0); while (w.next(nd, k)) if (k == 1) ++out[tv.var[nd]]; }
+  }
+
+  // G = [X Z]'[X Z]: constant over the whole run (hmc_mode 0)
+  void build_gram(const s4b_stan_data* sd) {
+    const int M = K_ + q_;
+    gram_.assign((size_t)M * M, 0.0);
+    std::vector<int> idx; std::vector<double> val;
+    for (int64_t i = 0; i < sd->N; ++i) {
+      idx.clear(); val.clear();
+      for (int k = 0; k < K_; ++k) { idx.push_back(k); val.push_back(sd->X[(size_t)k * sd->N + i]); }
+      if (q_) for (int e = sd->u[i]; e < sd->u[i + 1]; ++e) { idx.push_back(K_ + sd->v[e]); val.push_back(sd->w[e]); }
+      for (size_t a = 0; a < idx.size(); ++a) for (size_t b = 0; b < idx.size(); ++b) gram_[(size_t)idx[a] * M + idx[b]] += val[a] * val[b];
+    }
+  }
+  // ss = |e|^2, gX = X'e, gZ = Z'e with e = (y - offset) - X beta - Z b
+  double likelihood(const double* beta, const double* b, double* gX, double* gZ) {
+    if (hmcMode_ != 0) return dev_.leapfrog_sums(beta, b, gX, gZ);
+    const int M = K_ + q_;
+    double ss = s0_;
+    for (int a = 0; a < M; ++a) {
+      double ga = 0.0;
+      const double* row = &gram_[(size_t)a * M];
+      for (int k = 0; k < K_; ++k) ga += row[k] * beta[k];
+      for (int j = 0; j < q_; ++j) ga += row[K_ + j] * b[j];
+      double ca = a < K_ ? cX_[(size_t)a] : cZ_[(size_t)(a - K_)];
+      double th = a < K_ ? beta[a] : b[a - K_];
+      ss += th * (ga - 2.0 * ca);
+      if (a < K_) gX[a] = ca - ga; else gZ[a - K_] = ca - ga;
+    }
+    return ss;
+  }
+  void check_device() {
+    int32_t e = dev_.error_flags();
+    if (e & S4B_ERR_NODE_CAPACITY) throw std::runtime_error("a tree outgrew node_capacity; re-create the sampler with a larger bart_control.node_capacity");
+    if (e & S4B_ERR_TRACE_OVERFLOW) throw std::runtime_error("trace buffer overflow: call get_trace more often");
+  }
+
+  Dev dev_;
+  size_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 256, thin_ = 1, K_ = 0, q_ = 0, hmcMode_ = 0;
+  int warmup_ = 0, verbose_ = 0, offsetType_ = 0; bool keepFits_ = true, hasUserOffset_ = false;
+  std::vector<double> userOffset_;
+  s4b_callback_fn callback_ = nullptr; void* callbackUser_ = nullptr;
+  MTState rng_;
+  std::vector<int32_t> numCuts_; std::vector<std::vector<double>> cuts_;
+  ModelView hostModelView_;
+  std::unique_ptr<HostModel> model_; std::unique_ptr<Nuts> nuts_;
+  std::vector<double> row_, cX_, cZ_, gram_; double s0_ = 0, sigma_ = 1;
+  long treeUpdates_ = 0;
+};
+
+}  // namespace s4b
+#endif

@@ -1,0 +1,610 @@
+// Host side of the Stan block of the MI355X path.
+//
+// What stays on the host is O(D) per gradient: the unconstrain->constrain transforms, make_theta_L /
+// make_b, the priors and Jacobians of reference src/stan_files/continuous.stan:261-429, and the NUTS
+// control flow of reference src/include/stan/mcmc/hmc/nuts/base_nuts.hpp:78-352.  Everything O(N)
+// (X beta + Z b, residual sum of squares, X'e, Z'e) is produced by HIP kernels and enters through
+// the `Likelihood` callback, either once per Gibbs iteration as sufficient statistics
+// (c = [X Z]'(y - offset), s0 = |y - offset|^2 with the constant Gram matrix G = [X Z]'[X Z]) or once
+// per leapfrog (hmc_mode = 1).
+//
+// The O(D) part is differentiated with a small reverse-mode tape (the reference uses Stan's
+// reverse-mode AD: src/include/stan/math/rev/functor/gradient.hpp:46-56).
+#ifndef S4B_STAN_HOST_HPP
+#define S4B_STAN_HOST_HPP
+
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace s4b {
+
+// ---------------------------------------------------------------- reverse-mode tape
+class Tape {
+ public:
+  struct Op { double val; int a, b; double da, db; };
+  std::vector<Op> ops;
+  std::vector<double> adj;
+  void clear() { ops.clear(); }
+  int leaf(double v) { ops.push_back({v, -1, -1, 0, 0}); return (int)ops.size() - 1; }
+  int un(int a, double v, double da) { ops.push_back({v, a, -1, da, 0}); return (int)ops.size() - 1; }
+  int bin(int a, int b, double v, double da, double db) { ops.push_back({v, a, b, da, db}); return (int)ops.size() - 1; }
+  double val(int i) const { return ops[(size_t)i].val; }
+  // propagate: caller seeds adj (size = ops.size()) then calls backward()
+  void backward() {
+    for (int i = (int)ops.size() - 1; i >= 0; --i) {
+      const Op& o = ops[(size_t)i];
+      double g = adj[(size_t)i];
+      if (g == 0.0) continue;
+      if (o.a >= 0) adj[(size_t)o.a] += g * o.da;
+      if (o.b >= 0) adj[(size_t)o.b] += g * o.db;
+    }
+  }
+};
+
+struct TV {   // tape variable handle
+  Tape* t; int i;
+  double v() const { return t->val(i); }
+};
+inline TV operator+(TV a, TV b) { return {a.t, a.t->bin(a.i, b.i, a.v() + b.v(), 1, 1)}; }
+inline TV operator-(TV a, TV b) { return {a.t, a.t->bin(a.i, b.i, a.v() - b.v(), 1, -1)}; }
+inline TV operator*(TV a, TV b) { return {a.t, a.t->bin(a.i, b.i, a.v() * b.v(), b.v(), a.v())}; }
+inline TV operator/(TV a, TV b) { double r = a.v() / b.v(); return {a.t, a.t->bin(a.i, b.i, r, 1.0 / b.v(), -r / b.v())}; }
+inline TV operator+(TV a, double c) { return {a.t, a.t->un(a.i, a.v() + c, 1)}; }
+inline TV operator-(TV a, double c) { return {a.t, a.t->un(a.i, a.v() - c, 1)}; }
+inline TV operator*(TV a, double c) { return {a.t, a.t->un(a.i, a.v() * c, c)}; }
+inline TV operator*(double c, TV a) { return a * c; }
+inline TV operator/(TV a, double c) { return {a.t, a.t->un(a.i, a.v() / c, 1.0 / c)}; }
+inline TV operator-(double c, TV a) { return {a.t, a.t->un(a.i, c - a.v(), -1)}; }
+inline TV tsqrt(TV a) { double s = std::sqrt(a.v()); return {a.t, a.t->un(a.i, s, 0.5 / s)}; }
+inline TV texp(TV a) { double e = std::exp(a.v()); return {a.t, a.t->un(a.i, e, e)}; }
+inline TV tlog(TV a) { return {a.t, a.t->un(a.i, std::log(a.v()), 1.0 / a.v())}; }
+inline TV tsquare(TV a) { return {a.t, a.t->un(a.i, a.v() * a.v(), 2 * a.v())}; }
+inline TV tlog1m(TV a) { return {a.t, a.t->un(a.i, std::log1p(-a.v()), -1.0 / (1.0 - a.v()))}; }
+
+// ---------------------------------------------------------------- model description (the stanData list)
+struct StanSpec {
+  int64_t N = 0; int K = 0, q = 0, t = 0, len_theta_L = 0;
+  int is_binary = 0, prior_dist = 1, prior_dist_for_aux = 3;
+  std::vector<double> prior_scale, prior_mean, prior_df;
+  double prior_scale_for_aux = 1, prior_mean_for_aux = 0, prior_df_for_aux = 1;
+  std::vector<int> p, l;
+  std::vector<double> shape, scale, concentration, regularization;
+  // derived (continuous.stan transformed data, src/stan_sampler.cpp:167-182)
+  int len_z_T = 0, len_rho = 0, len_conc = 0, D = 0, n_constrained = 0;
+  std::vector<double> delta;
+  void finish() {
+    int sum_p = 0; len_z_T = 0; delta.clear();
+    for (int i = 0; i < t; ++i) {
+      sum_p += p[i];
+      if (p[i] > 1) for (int j = 0; j < p[i]; ++j) delta.push_back(concentration[(size_t)j]);
+      for (int j = 3; j <= p[i]; ++j) len_z_T += p[i] - 1;
+    }
+    len_rho = sum_p - t; len_conc = (int)delta.size();
+    D = K + q + len_z_T + len_rho + len_conc + t + (is_binary ? 0 : 1);
+    n_constrained = D + (is_binary ? 0 : 1) + K + q + len_theta_L;
+  }
+  int aux_pos() const { return D; }
+  int beta_pos() const { return D + (is_binary ? 0 : 1); }
+  int b_pos() const { return beta_pos() + K; }
+};
+
+// O(N) part: given beta, b, sigma returns ss = sum (y - offset - X beta - Z b)^2 and fills
+// gX = X'e, gZ = Z'e (e the residual).  Implemented by the device layer.
+typedef std::function<double(const double* beta, const double* b, double* gX, double* gZ)> Likelihood;
+
+class HostModel {
+ public:
+  StanSpec sp;
+  Likelihood lik;
+  long gradEvals = 0;
+  explicit HostModel(const StanSpec& s) : sp(s) { sp.finish(); }
+
+  struct Fwd { TV sigma; std::vector<TV> beta, b, theta_L, constrained; TV lp; };
+
+  void forward(Tape& tp, const std::vector<double>& qv, Fwd& F, std::vector<int>& qidx, bool jacobian) const {
+    tp.clear();
+    qidx.resize((size_t)sp.D);
+    for (int i = 0; i < sp.D; ++i) qidx[(size_t)i] = tp.leaf(qv[(size_t)i]);
+    auto Q = [&](int i) { return TV{&tp, qidx[(size_t)i]}; };
+    TV lp{&tp, tp.leaf(0.0)};
+    int pos = 0;
+    std::vector<TV> z_beta, z_b, z_T, rho, zeta, tau;
+    for (int k = 0; k < sp.K; ++k) z_beta.push_back(Q(pos++));
+    for (int j = 0; j < sp.q; ++j) z_b.push_back(Q(pos++));
+    for (int j = 0; j < sp.len_z_T; ++j) z_T.push_back(Q(pos++));
+    for (int j = 0; j < sp.len_rho; ++j) {   // lub_constrain(x, 0, 1): inv_logit, log-Jacobian -|x| - 2 log1p(exp(-|x|))
+      TV x = Q(pos++);
+      double il = 1.0 / (1.0 + std::exp(-x.v()));
+      rho.push_back(TV{&tp, tp.un(x.i, il, il * (1.0 - il))});
+      if (jacobian) {
+        double ax = std::fabs(x.v()), sg = x.v() >= 0 ? 1.0 : -1.0, e = std::exp(-ax);
+        lp = lp + TV{&tp, tp.un(x.i, -ax - 2.0 * std::log1p(e), -sg + 2.0 * sg * e / (1.0 + e))};
+      }
+    }
+    auto lb0 = [&](int idx) { TV x = Q(idx); if (jacobian) lp = lp + x; return texp(x); };
+    for (int j = 0; j < sp.len_conc; ++j) zeta.push_back(lb0(pos++));
+    for (int j = 0; j < sp.t; ++j) tau.push_back(lb0(pos++));
+    TV aux_unscaled{&tp, -1};
+    if (!sp.is_binary) aux_unscaled = lb0(pos++);
+
+    TV aux{&tp, tp.leaf(1.0)};
+    if (!sp.is_binary) {
+      if (sp.prior_dist_for_aux == 0) aux = aux_unscaled;
+      else { aux = aux_unscaled * sp.prior_scale_for_aux; if (sp.prior_dist_for_aux <= 2) aux = aux + sp.prior_mean_for_aux; }
+    }
+    F.sigma = aux;
+    F.beta.clear();
+    for (int k = 0; k < sp.K; ++k) {
+      if (sp.prior_dist == 0) F.beta.push_back(z_beta[(size_t)k]);
+      else if (sp.prior_dist == 1) F.beta.push_back(z_beta[(size_t)k] * sp.prior_scale[(size_t)k] + sp.prior_mean[(size_t)k]);
+      else F.beta.push_back(cornish_fisher(z_beta[(size_t)k], sp.prior_df[(size_t)k]) * sp.prior_scale[(size_t)k] + sp.prior_mean[(size_t)k]);
+    }
+    theta_L(tp, aux, tau, zeta, rho, z_T, F.theta_L);
+    make_b(tp, z_b, F.theta_L, F.b);
+    F.constrained.clear();
+    for (auto& x : z_beta) F.constrained.push_back(x);
+    for (auto& x : z_b) F.constrained.push_back(x);
+    for (auto& x : z_T) F.constrained.push_back(x);
+    for (auto& x : rho) F.constrained.push_back(x);
+    for (auto& x : zeta) F.constrained.push_back(x);
+    for (auto& x : tau) F.constrained.push_back(x);
+    if (!sp.is_binary) F.constrained.push_back(aux_unscaled);
+
+    const double HALF_LOG_2PI = 0.91893853320467274178;
+    if (!sp.is_binary && sp.prior_dist_for_aux > 0 && sp.prior_scale_for_aux > 0) {
+      const double log_half = -0.693147180559945286;
+      if (sp.prior_dist_for_aux == 1) lp = lp + (tsquare(aux_unscaled) * -0.5 - HALF_LOG_2PI) - log_half;
+      else if (sp.prior_dist_for_aux == 2) {
+        double nu = sp.prior_df_for_aux;
+        TV tt = tlog(tsquare(aux_unscaled) / nu + 1.0) * (-(nu + 1.0) / 2.0);
+        lp = lp + (tt + (std::lgamma((nu + 1.0) / 2.0) - std::lgamma(nu / 2.0) - 0.5 * std::log(nu * M_PI))) - log_half;
+      } else lp = lp - aux_unscaled;
+    }
+    if (sp.prior_dist == 1 || sp.prior_dist == 2) for (auto& z : z_beta) lp = lp + (tsquare(z) * -0.5 - HALF_LOG_2PI);
+    for (auto& z : z_b) lp = lp + (tsquare(z) * -0.5 - HALF_LOG_2PI);
+    for (auto& z : z_T) lp = lp + (tsquare(z) * -0.5 - HALF_LOG_2PI);
+    int pos_reg = 0, pos_rho = 0;
+    for (int i = 0; i < sp.t; ++i) if (sp.p[(size_t)i] > 1) {
+      int m = sp.p[(size_t)i] - 1;
+      std::vector<double> s1((size_t)m), s2((size_t)m);
+      double nu = sp.regularization[(size_t)pos_reg++] + 0.5 * (sp.p[(size_t)i] - 2);
+      s1[0] = nu; s2[0] = nu;
+      for (int j = 2; j <= m; ++j) { nu -= 0.5; s1[(size_t)j - 1] = 0.5 * j; s2[(size_t)j - 1] = nu; }
+      for (int j = 0; j < m; ++j) {
+        TV r = rho[(size_t)(pos_rho + j)];
+        double lbeta = std::lgamma(s1[(size_t)j]) + std::lgamma(s2[(size_t)j]) - std::lgamma(s1[(size_t)j] + s2[(size_t)j]);
+        lp = lp + (tlog(r) * (s1[(size_t)j] - 1.0) + tlog1m(r) * (s2[(size_t)j] - 1.0) - lbeta);
+      }
+      pos_rho += m;
+    }
+    for (int j = 0; j < sp.len_conc; ++j) lp = lp + (tlog(zeta[(size_t)j]) * (sp.delta[(size_t)j] - 1.0) - zeta[(size_t)j] - std::lgamma(sp.delta[(size_t)j]));
+    for (int j = 0; j < sp.t; ++j) lp = lp + (tlog(tau[(size_t)j]) * (sp.shape[(size_t)j] - 1.0) - tau[(size_t)j] - std::lgamma(sp.shape[(size_t)j]));
+    F.lp = lp;
+  }
+
+  double log_prob_grad(const std::vector<double>& qv, std::vector<double>& grad) {
+    ++gradEvals;
+    Fwd F; std::vector<int> qidx;
+    forward(tape_, qv, F, qidx, true);
+    std::vector<double> beta((size_t)sp.K), b((size_t)sp.q), gX((size_t)sp.K, 0.0), gZ((size_t)sp.q, 0.0);
+    for (int k = 0; k < sp.K; ++k) beta[(size_t)k] = F.beta[(size_t)k].v();
+    for (int j = 0; j < sp.q; ++j) b[(size_t)j] = F.b[(size_t)j].v();
+    double sigma = F.sigma.v();
+    double ss = lik(beta.data(), b.data(), gX.data(), gZ.data());
+    double s2 = sigma * sigma, N = (double)sp.N;
+    double ll = -0.5 * ss / s2 - N * std::log(sigma) - N * 0.91893853320467274178;
+    tape_.adj.assign(tape_.ops.size(), 0.0);
+    tape_.adj[(size_t)F.lp.i] = 1.0;
+    tape_.adj[(size_t)F.sigma.i] += ss / (s2 * sigma) - N / sigma;
+    for (int k = 0; k < sp.K; ++k) tape_.adj[(size_t)F.beta[(size_t)k].i] += gX[(size_t)k] / s2;
+    for (int j = 0; j < sp.q; ++j) tape_.adj[(size_t)F.b[(size_t)j].i] += gZ[(size_t)j] / s2;
+    tape_.backward();
+    grad.resize((size_t)sp.D);
+    for (int i = 0; i < sp.D; ++i) grad[(size_t)i] = tape_.adj[(size_t)qidx[(size_t)i]];
+    return F.lp.v() + ll;
+  }
+
+  // write_array_impl (continuous.hpp:2640-2938): constrained params, then aux, beta, b, theta_L
+  void write_array(const std::vector<double>& qv, double* out) {
+    Fwd F; std::vector<int> qidx;
+    forward(tape_, qv, F, qidx, false);
+    int o = 0;
+    for (auto& x : F.constrained) out[o++] = x.v();
+    if (!sp.is_binary) out[o++] = F.sigma.v();
+    for (auto& x : F.beta) out[o++] = x.v();
+    for (auto& x : F.b) out[o++] = x.v();
+    for (auto& x : F.theta_L) out[o++] = x.v();
+  }
+
+ private:
+  Tape tape_;
+  static TV cornish_fisher(TV z, double df) {
+    TV z2 = tsquare(z), z3 = z2 * z, z5 = z2 * z3, z7 = z2 * z5, z9 = z2 * z7;
+    double df2 = df * df, df3 = df2 * df, df4 = df2 * df2;
+    return z + (z3 + z) / (4 * df) + (z5 * 5.0 + z3 * 16.0 + z * 3.0) / (96 * df2) +
+           (z7 * 3.0 + z5 * 19.0 + z3 * 17.0 - z * 15.0) / (384 * df3) +
+           (z9 * 79.0 + z7 * 776.0 + z5 * 1482.0 - z3 * 1920.0 - z * 945.0) / (92160 * df4);
+  }
+  void theta_L(Tape& tp, TV dispersion, const std::vector<TV>& tau, const std::vector<TV>& zeta, const std::vector<TV>& rho,
+               const std::vector<TV>& z_T, std::vector<TV>& out) const {
+    out.clear();
+    int zeta_mark = 0, rho_mark = 0, z_T_mark = 0;
+    for (int i = 0; i < sp.t; ++i) {
+      int nc = sp.p[(size_t)i];
+      TV A = tau[(size_t)i] * sp.scale[(size_t)i] * dispersion;
+      if (nc == 1) { out.push_back(A); continue; }
+      TV zero{&tp, tp.leaf(0.0)};
+      std::vector<TV> T((size_t)(nc * nc), zero);
+      auto at = [&](int r, int c) -> TV& { return T[(size_t)(r * nc + c)]; };
+      TV trace = tsquare(A) * (double)nc;
+      TV sum_pi = zeta[(size_t)zeta_mark];
+      for (int j = 1; j < nc; ++j) sum_pi = sum_pi + zeta[(size_t)(zeta_mark + j)];
+      std::vector<TV> pi;
+      for (int j = 0; j < nc; ++j) pi.push_back(zeta[(size_t)(zeta_mark + j)] / sum_pi);
+      zeta_mark += nc;
+      TV std_dev = tsqrt(pi[0] * trace);
+      at(0, 0) = std_dev;
+      std_dev = tsqrt(pi[1] * trace);
+      TV T21 = rho[(size_t)rho_mark] * 2.0 - 1.0;
+      rho_mark += 1;
+      at(1, 1) = std_dev * tsqrt(1.0 - tsquare(T21));
+      at(1, 0) = std_dev * T21;
+      for (int r = 2; r <= nc - 1; ++r) {
+        TV dot = tsquare(z_T[(size_t)z_T_mark]);
+        for (int c = 1; c < r; ++c) dot = dot + tsquare(z_T[(size_t)(z_T_mark + c)]);
+        TV scale_factor = tsqrt(rho[(size_t)rho_mark] / dot) * std_dev;
+        for (int c = 0; c < r; ++c) at(r, c) = z_T[(size_t)(z_T_mark + c)] * scale_factor;
+        z_T_mark += r;
+        std_dev = tsqrt(pi[(size_t)r] * trace);
+        at(r, r) = tsqrt(1.0 - rho[(size_t)rho_mark]) * std_dev;
+        rho_mark += 1;
+      }
+      for (int c = 0; c < nc; ++c) for (int r = c; r < nc; ++r) out.push_back(at(r, c));
+    }
+  }
+  void make_b(Tape& tp, const std::vector<TV>& z_b, const std::vector<TV>& th, std::vector<TV>& b) const {
+    b.clear(); b.reserve((size_t)sp.q);
+    int b_mark = 0, tm = 0;
+    for (int i = 0; i < sp.t; ++i) {
+      int nc = sp.p[(size_t)i];
+      if (nc == 1) {
+        for (int s = 0; s < sp.l[(size_t)i]; ++s) b.push_back(th[(size_t)tm] * z_b[(size_t)(b_mark + s)]);
+        b_mark += sp.l[(size_t)i]; tm += 1;
+      } else {
+        std::vector<int> idx((size_t)(nc * nc), -1);   // theta_L index of T[r][c], column-major lower triangle
+        for (int c = 0; c < nc; ++c) for (int r = c; r < nc; ++r) idx[(size_t)(r * nc + c)] = tm++;
+        for (int j = 0; j < sp.l[(size_t)i]; ++j) {
+          for (int r = 0; r < nc; ++r) {
+            TV acc = th[(size_t)idx[(size_t)(r * nc)]] * z_b[(size_t)b_mark];
+            for (int c = 1; c <= r; ++c) acc = acc + th[(size_t)idx[(size_t)(r * nc + c)]] * z_b[(size_t)(b_mark + c)];
+            b.push_back(acc);
+          }
+          b_mark += nc;
+        }
+      }
+    }
+    (void)tp;
+  }
+};
+
+// ---------------------------------------------------------------- Stan's random stream
+// boost::ecuyer1988 + uniform_01 + uniform_real + ziggurat normal (see DESIGN.md "Random streams")
+class StanRng {
+ public:
+  void create(uint32_t seed, uint32_t chain) {
+    x1_ = seed % 2147483563u; if (!x1_) x1_ = 1;
+    x2_ = seed % 2147483399u; if (!x2_) x2_ = 1;
+    uint64_t z = (uint64_t(1) << 50) * chain;
+    x1_ = (uint32_t)(mulpow(40014, z, 2147483563ull) * x1_ % 2147483563ull);
+    x2_ = (uint32_t)(mulpow(40692, z, 2147483399ull) * x2_ % 2147483399ull);
+    build_tables();
+  }
+  uint32_t raw() {
+    x1_ = (uint32_t)(40014ull * x1_ % 2147483563ull);
+    x2_ = (uint32_t)(40692ull * x2_ % 2147483399ull);
+    return x2_ < x1_ ? x1_ - x2_ : x1_ - x2_ + 2147483562u;
+  }
+  double u01() { return (double)(raw() - 1u) / 2147483562.0; }
+  double uniform(double a, double b) { for (;;) { double r = u01() * (b - a) + a; if (r < b) return r; } }
+  double normal() {
+    for (;;) {
+      double u; int bucket; pair8(u, bucket);
+      int sign = (bucket & 1) * 2 - 1, i = bucket >> 1;
+      double x = u * nx_[i];
+      if (x < nx_[i + 1]) return x * sign;
+      if (i == 0) {
+        for (;;) { double tx = expo() / nx_[1], ty = expo(); if (2.0 * ty > tx * tx) return (tx + nx_[1]) * sign; }
+      }
+      double y = ny_[i] + u01() * (ny_[i + 1] - ny_[i]);
+      if (y < std::exp(-0.5 * x * x)) return x * sign;
+    }
+  }
+ private:
+  uint32_t x1_ = 1, x2_ = 1;
+  double nx_[129], ny_[129], ex_[257], ey_[257];
+  static uint64_t mulpow(uint64_t a, uint64_t e, uint64_t m) { uint64_t r = 1; a %= m; while (e) { if (e & 1) r = r * a % m; a = a * a % m; e >>= 1; } return r; }
+  uint32_t digit30() { uint32_t u; do { u = raw() - 1u; } while (u >= (1u << 30)); return u; }
+  void pair8(double& r, int& bucket) {   // 8 integer bits + 53-bit fraction out of three 30-bit digits
+    uint32_t a = digit30(), b = digit30(), c = digit30();
+    bucket = (int)(a & 255u);
+    r = std::ldexp((double)(a >> 8), -22);
+    r = std::ldexp(r + (double)b, -30);
+    r = 0.5 * (r + (double)(c & 1u));
+  }
+  double expo() {   // unit exponential, 256-layer ziggurat
+    double shift = 0.0;
+    for (;;) {
+      double u; int i; pair8(u, i);
+      double x = u * ex_[i];
+      if (x < ex_[i + 1]) return shift + x;
+      if (i == 0) { shift += ex_[1]; continue; }
+      double y = ey_[i] + u01() * (ey_[i + 1] - ey_[i]);
+      if (y < std::exp(-x)) return shift + x;
+    }
+  }
+  void build_tables() {
+    const double r = 3.442619855899, v = 9.91256303526217e-3;
+    nx_[1] = r; ny_[1] = std::exp(-0.5 * r * r); nx_[0] = v / ny_[1]; ny_[0] = 0;
+    for (int i = 2; i < 128; ++i) { ny_[i] = ny_[i - 1] + v / nx_[i - 1]; nx_[i] = std::sqrt(-2.0 * std::log(ny_[i])); }
+    nx_[128] = 0; ny_[128] = 1;
+    const double re = 7.69711747013104972, ve = 3.949659822581572e-3;
+    ex_[1] = re; ey_[1] = std::exp(-re); ex_[0] = ve / ey_[1]; ey_[0] = 0;
+    for (int i = 2; i < 256; ++i) { ey_[i] = ey_[i - 1] + ve / ex_[i - 1]; ex_[i] = -std::log(ey_[i]); }
+    ex_[256] = 0; ey_[256] = 1;
+  }
+};
+
+// ---------------------------------------------------------------- NUTS with diagonal metric adaptation
+struct NutsControl {
+  uint32_t seed = 0; double init_r = 2.0; int skip = 1;
+  double gamma = 0.05, delta = 0.8, kappa = 0.75, t0 = 10;
+  unsigned init_buffer = 75, term_buffer = 50, window = 25;
+  double stepsize = 1, jitter = 0; int max_depth = 10;
+};
+
+class Nuts {
+ public:
+  typedef std::vector<double> V;
+  struct Pt { V q, p, g; double Vv = 0; };
+
+  Nuts(HostModel& m, const NutsControl& c, unsigned chain, int num_warmup) : model_(m), D_(m.sp.D), skip_(c.skip) {
+    rng_.create(c.seed, chain);
+    // services::util::initialize: uniform(-R, R) starts, at most 100 attempts
+    bool ok = false;
+    for (int attempt = 0; attempt < (c.init_r == 0 ? 1 : 100) && !ok; ++attempt) {
+      cont_.assign((size_t)D_, 0.0);
+      if (c.init_r != 0) for (int i = 0; i < D_; ++i) cont_[(size_t)i] = rng_.uniform(-c.init_r, c.init_r);
+      V g;
+      double lp = model_.log_prob_grad(cont_, g);
+      if (!std::isfinite(lp)) continue;
+      lp = model_.log_prob_grad(cont_, g);
+      double s = 0; for (double x : g) s += x;
+      ok = std::isfinite(s);
+    }
+    if (!ok) throw std::domain_error("Initialization failed.");
+    inv_metric_.assign((size_t)D_, 1.0);
+    z_.q = cont_; z_.p.assign((size_t)D_, 0.0); z_.g.assign((size_t)D_, 0.0);
+    wm_.assign((size_t)D_, 0.0); wm2_.assign((size_t)D_, 0.0);
+    if (c.stepsize > 0) nom_eps_ = c.stepsize;
+    if (c.jitter > 0 && c.jitter < 1) jitter_ = c.jitter;
+    if (c.max_depth > 0) max_depth_ = c.max_depth;
+    mu_ = std::log(10 * c.stepsize);
+    if (c.delta > 0 && c.delta < 1) delta_ = c.delta;
+    if (c.gamma > 0) gamma_ = c.gamma;
+    if (c.kappa > 0) kappa_ = c.kappa;
+    if (c.t0 > 0) t0_ = c.t0;
+    next_window_ = init_buffer_ + window_size_ - 1;   // restart() with the zero defaults
+    set_windows((unsigned)(num_warmup * c.skip), c.init_buffer, c.term_buffer, c.window);
+    init_stepsize();
+  }
+
+  // interruptable_sampler::run: skip-1 unsaved transitions then one saved; fills the sample row
+  void run(double* row) {
+    for (int s = 0; s < skip_; ++s) transition();
+    row[0] = lp_; row[1] = accept_; row[2] = eps_; row[3] = depth_; row[4] = n_leapfrog_; row[5] = divergent_ ? 1 : 0; row[6] = energy_;
+    model_.write_array(cont_, row + 7);
+  }
+  void disengage() { adapting_ = false; nom_eps_ = std::exp(x_bar_); }
+
+ private:
+  HostModel& model_; int D_, skip_;
+  StanRng rng_;
+  Pt z_; V inv_metric_, cont_;
+  double nom_eps_ = 0.1, eps_ = 0.1, jitter_ = 0; int max_depth_ = 10;
+  double lp_ = 0, accept_ = 0, energy_ = 0; int depth_ = 0, n_leapfrog_ = 0; bool divergent_ = false, adapting_ = true;
+  double mu_ = 0.5, delta_ = 0.5, gamma_ = 0.05, kappa_ = 0.75, t0_ = 10, counter_ = 0, s_bar_ = 0, x_bar_ = 0;
+  unsigned num_warmup_ = 0, init_buffer_ = 0, term_buffer_ = 0, base_window_ = 0, window_counter_ = 0, next_window_ = 0, window_size_ = 0;
+  double wn_ = 0; V wm_, wm2_;
+
+  double kinetic() const { double s = 0; for (int i = 0; i < D_; ++i) s += z_.p[(size_t)i] * (inv_metric_[(size_t)i] * z_.p[(size_t)i]); return 0.5 * s; }
+  double hamiltonian() const { return kinetic() + z_.Vv; }
+  void grad() { z_.Vv = -model_.log_prob_grad(z_.q, z_.g); for (double& x : z_.g) x = -x; }
+  void draw_momentum() { for (int i = 0; i < D_; ++i) z_.p[(size_t)i] = rng_.normal() / std::sqrt(inv_metric_[(size_t)i]); }
+  void leapfrog(double e) {
+    for (int i = 0; i < D_; ++i) z_.p[(size_t)i] -= (0.5 * e) * z_.g[(size_t)i];
+    for (int i = 0; i < D_; ++i) z_.q[(size_t)i] += e * (inv_metric_[(size_t)i] * z_.p[(size_t)i]);
+    grad();
+    for (int i = 0; i < D_; ++i) z_.p[(size_t)i] -= (0.5 * e) * z_.g[(size_t)i];
+  }
+  V sharp() const { V r((size_t)D_); for (int i = 0; i < D_; ++i) r[(size_t)i] = inv_metric_[(size_t)i] * z_.p[(size_t)i]; return r; }
+  static double finite_or_inf(double h) { return std::isnan(h) ? std::numeric_limits<double>::infinity() : h; }
+
+  void init_stepsize() {
+    Pt z0 = z_;
+    if (nom_eps_ == 0 || nom_eps_ > 1e7 || std::isnan(nom_eps_)) return;
+    const double thr = std::log(0.8);
+    draw_momentum(); grad();
+    double H0 = hamiltonian();
+    leapfrog(nom_eps_);
+    double dH = H0 - finite_or_inf(hamiltonian());
+    int dir = dH > thr ? 1 : -1;
+    for (;;) {
+      z_ = z0;
+      draw_momentum(); grad();
+      double H0b = hamiltonian();
+      leapfrog(nom_eps_);
+      double d = H0b - finite_or_inf(hamiltonian());
+      if (dir == 1 && !(d > thr)) break;
+      if (dir == -1 && !(d < thr)) break;
+      nom_eps_ = dir == 1 ? 2 * nom_eps_ : 0.5 * nom_eps_;
+      if (nom_eps_ > 1e7) throw std::runtime_error("Posterior is improper. Please check your model.");
+      if (nom_eps_ == 0) throw std::runtime_error("No acceptably small step size could be found. Perhaps the posterior is not continuous?");
+    }
+    z_ = z0;
+  }
+
+  static double lse(double a, double b) {
+    const double ninf = -std::numeric_limits<double>::infinity();
+    if (a == ninf) return b;
+    if (b == ninf) return a;
+    return a > b ? a + std::log1p(std::exp(b - a)) : b + std::log1p(std::exp(a - b));
+  }
+  static bool uturn_ok(const V& sharp_minus, const V& sharp_plus, const V& rho) {
+    double a = 0, b = 0;
+    for (size_t i = 0; i < rho.size(); ++i) { a += sharp_plus[i] * rho[i]; b += sharp_minus[i] * rho[i]; }
+    return a > 0 && b > 0;
+  }
+  static V vsum(const V& a, const V& b) { V r(a.size()); for (size_t i = 0; i < a.size(); ++i) r[i] = a[i] + b[i]; return r; }
+
+  struct Acc { int n_leapfrog = 0; double sum_metro = 0; };
+
+  bool subtree(int depth, Pt& propose, V& sharp_beg, V& sharp_end, V& rho, V& p_beg, V& p_end, double H0, double sign,
+               double& lsw, Acc& acc) {
+    const double ninf = -std::numeric_limits<double>::infinity();
+    if (depth == 0) {
+      leapfrog(sign * eps_);
+      ++acc.n_leapfrog;
+      double h = finite_or_inf(hamiltonian());
+      if (h - H0 > 1000.0) divergent_ = true;
+      lsw = lse(lsw, H0 - h);
+      acc.sum_metro += (H0 - h > 0) ? 1.0 : std::exp(H0 - h);
+      propose = z_;
+      sharp_beg = sharp(); sharp_end = sharp_beg;
+      for (int i = 0; i < D_; ++i) rho[(size_t)i] += z_.p[(size_t)i];
+      p_beg = z_.p; p_end = p_beg;
+      return !divergent_;
+    }
+    double lsw_init = ninf;
+    V p_init_end((size_t)D_), sharp_init_end((size_t)D_), rho_init((size_t)D_, 0.0);
+    if (!subtree(depth - 1, propose, sharp_beg, sharp_init_end, rho_init, p_beg, p_init_end, H0, sign, lsw_init, acc)) return false;
+    Pt propose_final = z_;
+    double lsw_final = ninf;
+    V p_final_beg((size_t)D_), sharp_final_beg((size_t)D_), rho_final((size_t)D_, 0.0);
+    if (!subtree(depth - 1, propose_final, sharp_final_beg, sharp_end, rho_final, p_final_beg, p_end, H0, sign, lsw_final, acc)) return false;
+    double lsw_sub = lse(lsw_init, lsw_final);
+    lsw = lse(lsw, lsw_sub);
+    if (lsw_final > lsw_sub) propose = propose_final;
+    else if (rng_.u01() < std::exp(lsw_final - lsw_sub)) propose = propose_final;
+    V rho_sub = vsum(rho_init, rho_final);
+    for (int i = 0; i < D_; ++i) rho[(size_t)i] += rho_sub[(size_t)i];
+    bool ok = uturn_ok(sharp_beg, sharp_end, rho_sub);
+    ok &= uturn_ok(sharp_beg, sharp_final_beg, vsum(rho_init, p_final_beg));
+    ok &= uturn_ok(sharp_init_end, sharp_end, vsum(rho_final, p_init_end));
+    return ok;
+  }
+
+  void nuts_transition() {
+    const double ninf = -std::numeric_limits<double>::infinity();
+    eps_ = nom_eps_;
+    if (jitter_) eps_ *= 1.0 + jitter_ * (2.0 * rng_.u01() - 1.0);
+    z_.q = cont_;
+    draw_momentum(); grad();
+    Pt fwd = z_, bck = z_, sample = z_, propose = z_;
+    V p_ff = z_.p, s_ff = sharp(), p_fb = z_.p, s_fb = s_ff, p_bf = z_.p, s_bf = s_ff, p_bb = z_.p, s_bb = s_ff;
+    V rho = z_.p;
+    double lsw = 0, H0 = hamiltonian();
+    Acc acc;
+    depth_ = 0; divergent_ = false;
+    while (depth_ < max_depth_) {
+      V rho_f((size_t)D_, 0.0), rho_b((size_t)D_, 0.0);
+      bool valid; double lsw_sub = ninf;
+      if (rng_.u01() > 0.5) {
+        z_ = fwd; rho_b = rho; p_bf = p_ff; s_bf = s_ff;
+        valid = subtree(depth_, propose, s_fb, s_ff, rho_f, p_fb, p_ff, H0, 1, lsw_sub, acc);
+        fwd = z_;
+      } else {
+        z_ = bck; rho_f = rho; p_fb = p_bb; s_fb = s_bb;
+        valid = subtree(depth_, propose, s_bf, s_bb, rho_b, p_bf, p_bb, H0, -1, lsw_sub, acc);
+        bck = z_;
+      }
+      if (!valid) break;
+      ++depth_;
+      if (lsw_sub > lsw) sample = propose;
+      else if (rng_.u01() < std::exp(lsw_sub - lsw)) sample = propose;
+      lsw = lse(lsw, lsw_sub);
+      rho = vsum(rho_b, rho_f);
+      bool ok = uturn_ok(s_bb, s_ff, rho);
+      ok &= uturn_ok(s_bb, s_fb, vsum(rho_b, p_fb));
+      ok &= uturn_ok(s_bf, s_ff, vsum(rho_f, p_bf));
+      if (!ok) break;
+    }
+    n_leapfrog_ = acc.n_leapfrog;
+    accept_ = acc.sum_metro / (double)acc.n_leapfrog;
+    z_ = sample;
+    energy_ = hamiltonian();
+    cont_ = z_.q; lp_ = -z_.Vv;
+  }
+
+  void transition() {
+    nuts_transition();
+    if (!adapting_) return;
+    // dual averaging
+    ++counter_;
+    double a = accept_ > 1 ? 1 : accept_;
+    double eta = 1.0 / (counter_ + t0_);
+    s_bar_ = (1.0 - eta) * s_bar_ + eta * (delta_ - a);
+    double x = mu_ - s_bar_ * std::sqrt(counter_) / gamma_;
+    double x_eta = std::pow(counter_, -kappa_);
+    x_bar_ = (1.0 - x_eta) * x_bar_ + x_eta * x;
+    nom_eps_ = std::exp(x);
+    // windowed variance
+    bool in_window = window_counter_ >= init_buffer_ && window_counter_ < num_warmup_ - term_buffer_ && window_counter_ != num_warmup_;
+    if (in_window) {
+      ++wn_;
+      for (int i = 0; i < D_; ++i) { double d = z_.q[(size_t)i] - wm_[(size_t)i]; wm_[(size_t)i] += d / wn_; wm2_[(size_t)i] += d * (z_.q[(size_t)i] - wm_[(size_t)i]); }
+    }
+    bool window_end = window_counter_ == next_window_ && window_counter_ != num_warmup_;
+    if (window_end) {
+      next_window();
+      for (int i = 0; i < D_; ++i) {
+        double var = wn_ > 1 ? wm2_[(size_t)i] / (wn_ - 1.0) : inv_metric_[(size_t)i];
+        inv_metric_[(size_t)i] = (wn_ / (wn_ + 5.0)) * var + 1e-3 * (5.0 / (wn_ + 5.0));
+      }
+      wn_ = 0; wm_.assign((size_t)D_, 0.0); wm2_.assign((size_t)D_, 0.0);
+      ++window_counter_;
+      init_stepsize();
+      mu_ = std::log(10 * nom_eps_);
+      counter_ = 0; s_bar_ = 0; x_bar_ = 0;
+      return;
+    }
+    ++window_counter_;
+  }
+  void set_windows(unsigned num_warmup, unsigned init_buffer, unsigned term_buffer, unsigned base_window) {
+    if (num_warmup < 20) return;
+    if (init_buffer + base_window + term_buffer > num_warmup) {
+      num_warmup_ = num_warmup;
+      init_buffer_ = (unsigned)(0.15 * num_warmup);
+      term_buffer_ = (unsigned)(0.10 * num_warmup);
+      base_window_ = num_warmup - (init_buffer_ + term_buffer_);
+      return;   // the vendored Stan does not restart() here (windowed_adaptation.hpp:45-74)
+    }
+    num_warmup_ = num_warmup; init_buffer_ = init_buffer; term_buffer_ = term_buffer; base_window_ = base_window;
+    window_counter_ = 0; window_size_ = base_window_; next_window_ = init_buffer_ + window_size_ - 1;
+  }
+  void next_window() {
+    if (next_window_ == num_warmup_ - term_buffer_ - 1) return;
+    window_size_ *= 2;
+    next_window_ = window_counter_ + window_size_;
+    if (next_window_ == num_warmup_ - term_buffer_ - 1) return;
+    unsigned boundary = next_window_ + 2 * window_size_;
+    if (boundary >= num_warmup_ - term_buffer_) next_window_ = num_warmup_ - term_buffer_ - 1;
+  }
+};
+
+}  // namespace s4b
+#endif

@@ -1,0 +1,259 @@
+// TEST INFRASTRUCTURE ONLY — CPU emulation of the device layer interface used by
+// stan4bart_amd/csrc/sampler_core.hpp.  It lets the `-m "not gpu"` tests exercise the product's host
+// logic (Gibbs order, NUTS, tape gradient, propose/decide control code, C-ABI) in a container without a
+// GPU.  It is never linked into the product library: the product's only device layer is dev_hip.hip,
+// and the product fails loudly when no GPU is present.  Kernels are restated here as plain loops with
+// the same per-observation arithmetic as the HIP kernels (reduction ORDER differs, as it does on the GPU).
+#ifndef S4B_DEV_CPU_HPP
+#define S4B_DEV_CPU_HPP
+
+#include <cstring>
+#include <vector>
+#include "../../stan4bart_amd/csrc/sampler_core.hpp"
+
+namespace s4b {
+
+class DevCpu {
+ public:
+  void init(const DevInit& d) {
+    di_ = d;
+    n_ = (size_t)d.n; nTest_ = (size_t)d.nTest; P_ = d.P; T_ = d.T; nc_ = d.nc; K_ = d.K; q_ = d.q;
+    xbin_.assign(d.xbin, d.xbin + (size_t)P_ * n_);
+    if (nTest_) xbinTest_.assign(d.xbinTest, d.xbinTest + (size_t)P_ * nTest_);
+    numCuts_.assign(d.numCuts, d.numCuts + P_);
+    y_.assign(d.y, d.y + n_);
+    if (d.userOffset) user_.assign(d.userOffset, d.userOffset + n_);
+    X_.assign(d.X, d.X + n_ * (size_t)K_);
+    if (d.nnz) { w_.assign(d.w, d.w + d.nnz); v_.assign(d.v, d.v + d.nnz); }
+    u_.assign(n_ + 1, 0); if (d.u) u_.assign(d.u, d.u + n_ + 1);
+    R_.assign(n_, 0.0); off_.assign(n_, 0.0); offNew_.assign(n_, 0.0); e0_.assign(n_, 0.0);
+    leaf_.assign((size_t)T_ * n_, 0);
+    size_t m = (size_t)T_ * nc_;
+    var_.assign(m, NODE_FREE); left_.assign(m, -1); right_.assign(m, -1); parent_.assign(m, -1); cut_.assign(m, 0); mu_.assign(m, 0.0); cnt_.assign(m, 0);
+    hwm_.assign((size_t)T_, 1);
+    for (int t = 0; t < T_; ++t) var_[(size_t)t * nc_] = NODE_LEAF;
+    for (int s = 0; s < 2; ++s) {
+      sc_[s].pvar.assign((size_t)nc_, 0); sc_[s].pleft.assign((size_t)nc_, 0); sc_[s].pright.assign((size_t)nc_, 0); sc_[s].pparent.assign((size_t)nc_, 0);
+      sc_[s].pcut.assign((size_t)nc_, 0); sc_[s].binA.assign((size_t)nc_, 0); sc_[s].binB.assign((size_t)nc_, 0); sc_[s].list.assign((size_t)nc_, 0);
+      sc_[s].insub.assign((size_t)nc_, 0); sc_[s].muOld.assign((size_t)nc_, 0.0);
+    }
+    binCnt_.assign((size_t)2 * nc_, 0.0); binSum_.assign((size_t)2 * nc_, 0.0);
+    trace_.assign((size_t)d.traceCap, StepRecord{});
+    // arrays view
+    a_ = BartArrays{};
+    a_.n = d.n; a_.npad = d.n; a_.P = P_; a_.T = T_; a_.nc = nc_; a_.grid = 1; a_.binCap = 2 * nc_; a_.traceCap = d.traceCap;
+    a_.nTest = d.nTest; a_.nTestPad = d.nTest;
+    a_.xbin = xbin_.data(); a_.xbinTest = xbinTest_.data(); a_.y = y_.data(); a_.R = R_.data(); a_.off = off_.data(); a_.offNew = offNew_.data();
+    a_.userOffset = user_.empty() ? nullptr : user_.data(); a_.leaf = leaf_.data();
+    a_.var = var_.data(); a_.left = left_.data(); a_.right = right_.data(); a_.parent = parent_.data(); a_.cut = cut_.data(); a_.mu = mu_.data();
+    a_.cnt = cnt_.data(); a_.hwm = hwm_.data();
+    for (int s = 0; s < 2; ++s) {
+      StepScratch& c = a_.sc[s];
+      c.pvar = sc_[s].pvar.data(); c.pleft = sc_[s].pleft.data(); c.pright = sc_[s].pright.data(); c.pparent = sc_[s].pparent.data(); c.pcut = sc_[s].pcut.data();
+      c.binA = sc_[s].binA.data(); c.binB = sc_[s].binB.data(); c.list = sc_[s].list.data(); c.insub = sc_[s].insub.data(); c.muOld = sc_[s].muOld.data();
+      c.prop = &sc_[s].prop; c.accepted = &sc_[s].accepted;
+    }
+    a_.partCnt = nullptr; a_.partSum = nullptr; a_.binCnt = binCnt_.data(); a_.binSum = binSum_.data();
+    a_.rng = &rng_; a_.scale = &scale_; a_.numCuts = numCuts_.data();
+    a_.trace = trace_.data(); a_.traceCount = &traceCount_; a_.errFlag = &err_;
+    a_.model = d.model; a_.model.numCuts = numCuts_.data(); a_.traceOn = 0;
+    // initial scale from the raw response, offset 0; R = yRescaled (all tree fits are zero)
+    double mn = y_[0], mx = y_[0];
+    for (size_t i = 1; i < n_; ++i) { if (y_[i] < mn) mn = y_[i]; if (y_[i] > mx) mx = y_[i]; }
+    scale_ = ScaleState{}; scale_.min = mn; scale_.max = mx; scale_.range = mx - mn; scale_.min0 = mn; scale_.range0 = mx - mn; scale_.sigmaData = 1.0; scale_.sigma = 1.0 / (mx - mn);
+    for (size_t i = 0; i < n_; ++i) R_[i] = (y_[i] - mn) / scale_.range - 0.5;
+  }
+
+  void upload_rng(const MTState& s) { rng_ = s; }
+  void download_rng(MTState& s) { s = rng_; }
+  void upload_trees(const int16_t* var, const uint16_t* cut, const int16_t* left, const int16_t* right, const int16_t* parent, const double* mu, const int32_t* hwm) {
+    size_t m = (size_t)T_ * nc_;
+    std::memcpy(var_.data(), var, m * 2); std::memcpy(cut_.data(), cut, m * 2); std::memcpy(left_.data(), left, m * 2); std::memcpy(right_.data(), right, m * 2);
+    std::memcpy(parent_.data(), parent, m * 2); std::memcpy(mu_.data(), mu, m * 8); std::memcpy(hwm_.data(), hwm, (size_t)T_ * 4);
+  }
+  void download_trees(int16_t* var, uint16_t* cut, int16_t* left, int16_t* right, int16_t* parent, double* mu, int32_t* cnt, int32_t* hwm) {
+    size_t m = (size_t)T_ * nc_;
+    std::memcpy(var, var_.data(), m * 2); std::memcpy(cut, cut_.data(), m * 2); std::memcpy(left, left_.data(), m * 2); std::memcpy(right, right_.data(), m * 2);
+    std::memcpy(parent, parent_.data(), m * 2); std::memcpy(mu, mu_.data(), m * 8); std::memcpy(cnt, cnt_.data(), m * 4); std::memcpy(hwm, hwm_.data(), (size_t)T_ * 4);
+  }
+  void download_leaf_plane(int t, uint16_t* out) { std::memcpy(out, &leaf_[(size_t)t * n_], n_ * 2); }
+  void get_scale(ScaleState& s) { s = scale_; }
+  int32_t error_flags() { return err_; }
+  int64_t launches() const { return launches_; }
+  void set_trace(bool on) { a_.traceOn = on ? 1 : 0; traceCount_ = 0; }
+  int64_t get_trace(int64_t cap, int32_t* out) {
+    int64_t m = traceCount_;
+    for (int64_t i = 0; i < m && i < cap; ++i) std::memcpy(out + 5 * i, &trace_[(size_t)i], 20);
+    traceCount_ = 0;
+    return m;
+  }
+
+  // ---- offsets and response rescaling (dbarts setOffset / setSigma)
+  void offset_from_host(const double* off) { std::memcpy(offNew_.data(), off, n_ * 8); }
+  void offset_from_params(const double* beta, const double* b, int fixed, int random, int addUser) {
+    for (size_t i = 0; i < n_; ++i) {
+      double eta = 0.0;
+      if (fixed) for (int k = 0; k < K_; ++k) eta += X_[(size_t)k * n_ + i] * beta[k];
+      if (random && q_) for (int e = u_[i]; e < u_[i + 1]; ++e) eta += w_[(size_t)e] * b[v_[(size_t)e]];
+      if (addUser) eta += user_[i];
+      offNew_[i] = eta;
+    }
+  }
+  void param_mean_to_host(const double* beta, const double* b, double* out) {
+    for (size_t i = 0; i < n_; ++i) {
+      double eta = 0.0;
+      for (int k = 0; k < K_; ++k) eta += X_[(size_t)k * n_ + i] * beta[k];
+      if (q_) for (int e = u_[i]; e < u_[i + 1]; ++e) eta += w_[(size_t)e] * b[v_[(size_t)e]];
+      out[i] = eta;
+    }
+  }
+  void set_sigma(double s) { scale_.sigmaData = s; scale_.sigma = s / scale_.range; }
+  void rescale(bool update) {
+    ScaleState& s = scale_;
+    s.min0 = s.min; s.range0 = s.range; s.shiftPerTree = 0.0;
+    if (update) {
+      double mn = y_[0] - offNew_[0], mx = mn;
+      for (size_t i = 1; i < n_; ++i) { double v = y_[i] - offNew_[i]; if (v < mn) mn = v; if (v > mx) mx = v; }
+      s.min = mn; s.max = mx; s.range = mx - mn;
+      s.shiftPerTree = (s.min0 + 0.5 * s.range0 - s.min - 0.5 * s.range) / (double)T_;
+      s.sigma = s.sigmaData / s.range;
+      for (size_t k = 0; k < mu_.size(); ++k) mu_[k] = (s.range0 * mu_[k] + s.shiftPerTree) / s.range;
+    }
+    for (size_t i = 0; i < n_; ++i) {
+      double yOld = (y_[i] - off_[i] - s.min0) / s.range0 - 0.5;
+      double F = yOld - R_[i];
+      if (update) F = (s.range0 * F + (double)T_ * s.shiftPerTree) / s.range;
+      double yNew = (y_[i] - offNew_[i] - s.min) / s.range - 0.5;
+      R_[i] = yNew - F;
+    }
+    off_.swap(offNew_);
+    a_.off = off_.data(); a_.offNew = offNew_.data();
+  }
+
+  // ---- trees
+  void assign_leaves_and_residual() {
+    for (size_t i = 0; i < n_; ++i) R_[i] = (y_[i] - off_[i] - scale_.min) / scale_.range - 0.5;
+    for (int t = 0; t < T_; ++t) {
+      TreeView tv = tree_view(a_, t);
+      for (size_t i = 0; i < n_; ++i) {
+        int nd = 0;
+        while (tv.var[nd] >= 0) nd = (xbin_[(size_t)tv.var[nd] * n_ + i] <= tv.cut[nd]) ? tv.left[nd] : tv.right[nd];
+        leaf_[(size_t)t * n_ + i] = (uint16_t)nd;
+        R_[i] -= mu_[(size_t)t * nc_ + nd];
+      }
+    }
+  }
+  void sweep(int thin) {
+    for (int k = 0; k < thin; ++k) {
+      propose_step(a_, 0); ++launches_;
+      for (int t = 0; t < T_; ++t) {
+        stats(t); ++launches_;
+        control_step(a_, t, t + 1 < T_ ? t + 1 : -1); ++launches_;
+        apply(t); ++launches_;
+      }
+    }
+  }
+  void test_fits(double* out) {
+    for (size_t i = 0; i < nTest_; ++i) {
+      double f = 0.0;
+      for (int t = 0; t < T_; ++t) {
+        TreeView tv = tree_view(a_, t);
+        int nd = 0;
+        while (tv.var[nd] >= 0) nd = (xbinTest_[(size_t)tv.var[nd] * nTest_ + i] <= tv.cut[nd]) ? tv.left[nd] : tv.right[nd];
+        f += mu_[(size_t)t * nc_ + nd];
+      }
+      out[i] = (f + 0.5) * scale_.range + scale_.min;
+    }
+  }
+
+  // ---- Stan inputs
+  void stan_inputs(int mode, bool wantTrain, double* cX, double* cZ, double* s0, double* trainOut) {
+    double ss = 0.0;
+    for (int k = 0; k < K_; ++k) cX[k] = 0.0;
+    for (int j = 0; j < q_; ++j) cZ[j] = 0.0;
+    for (size_t i = 0; i < n_; ++i) {
+      double fit = 0.0;
+      if (mode != 0) {
+        double yr = (y_[i] - off_[i] - scale_.min) / scale_.range - 0.5;
+        fit = ((yr - R_[i]) + 0.5) * scale_.range + scale_.min;
+      }
+      double so = mode == 0 ? 0.0 : mode == 1 ? fit : mode == 2 ? user_[i] : fit + user_[i];
+      double e = y_[i] - so;
+      e0_[i] = e;
+      ss += e * e;
+      for (int k = 0; k < K_; ++k) cX[k] += X_[(size_t)k * n_ + i] * e;
+      if (q_) for (int z = u_[i]; z < u_[i + 1]; ++z) cZ[v_[(size_t)z]] += w_[(size_t)z] * e;
+      if (wantTrain && trainOut) trainOut[i] = fit;
+    }
+    *s0 = ss;
+  }
+  double leapfrog_sums(const double* beta, const double* b, double* gX, double* gZ) {
+    double ss = 0.0;
+    for (int k = 0; k < K_; ++k) gX[k] = 0.0;
+    for (int j = 0; j < q_; ++j) gZ[j] = 0.0;
+    for (size_t i = 0; i < n_; ++i) {
+      double e = e0_[i];
+      for (int k = 0; k < K_; ++k) e -= X_[(size_t)k * n_ + i] * beta[k];
+      if (q_) for (int z = u_[i]; z < u_[i + 1]; ++z) e -= w_[(size_t)z] * b[v_[(size_t)z]];
+      ss += e * e;
+      for (int k = 0; k < K_; ++k) gX[k] += X_[(size_t)k * n_ + i] * e;
+      if (q_) for (int z = u_[i]; z < u_[i + 1]; ++z) gZ[v_[(size_t)z]] += w_[(size_t)z] * e;
+    }
+    return ss;
+  }
+
+ private:
+  void stats(int t) {
+    const StepScratch& c = a_.sc[t & 1];
+    const Proposal& pr = *c.prop;
+    int nb = pr.nbA + pr.nbB;
+    for (int k = 0; k < nb; ++k) { binCnt_[(size_t)k] = 0.0; binSum_[(size_t)k] = 0.0; }
+    const double* mu = &mu_[(size_t)t * nc_];
+    const uint16_t* leaf = &leaf_[(size_t)t * n_];
+    for (size_t i = 0; i < n_; ++i) {
+      int lf = leaf[i];
+      double r = R_[i] + mu[lf];
+      int a = c.binA[lf];
+      binCnt_[(size_t)a] += 1.0; binSum_[(size_t)a] += r;
+      if (c.insub[lf]) {
+        int nd = pr.node;
+        while (c.pvar[nd] >= 0) nd = (xbin_[(size_t)c.pvar[nd] * n_ + i] <= c.pcut[nd]) ? c.pleft[nd] : c.pright[nd];
+        int b = c.binB[nd];
+        binCnt_[(size_t)b] += 1.0; binSum_[(size_t)b] += r;
+      }
+    }
+  }
+  void apply(int t) {
+    const StepScratch& c = a_.sc[t & 1];
+    const Proposal& pr = *c.prop;
+    TreeView tv = tree_view(a_, t);
+    const double* mu = &mu_[(size_t)t * nc_];
+    uint16_t* leaf = &leaf_[(size_t)t * n_];
+    const bool acc = *c.accepted != 0;
+    for (size_t i = 0; i < n_; ++i) {
+      int lf = leaf[i], nl = lf;
+      if (acc && c.insub[lf]) {
+        int nd = pr.node;
+        while (tv.var[nd] >= 0) nd = (xbin_[(size_t)tv.var[nd] * n_ + i] <= tv.cut[nd]) ? tv.left[nd] : tv.right[nd];
+        nl = nd; leaf[i] = (uint16_t)nd;
+      }
+      R_[i] = (R_[i] + c.muOld[lf]) - mu[nl];
+    }
+  }
+
+  struct Scratch { std::vector<int16_t> pvar, pleft, pright, pparent, binA, binB, list; std::vector<uint16_t> pcut; std::vector<uint8_t> insub;
+                   std::vector<double> muOld; Proposal prop; int32_t accepted = 0; };
+  DevInit di_;
+  size_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0;
+  std::vector<uint16_t> xbin_, xbinTest_, leaf_, cut_;
+  std::vector<int32_t> numCuts_, cnt_, hwm_, v_, u_;
+  std::vector<double> y_, user_, X_, w_, R_, off_, offNew_, e0_, mu_, binCnt_, binSum_;
+  std::vector<int16_t> var_, left_, right_, parent_;
+  Scratch sc_[2];
+  std::vector<StepRecord> trace_;
+  MTState rng_; ScaleState scale_; BartArrays a_;
+  int32_t traceCount_ = 0, err_ = 0; int64_t launches_ = 0;
+};
+
+}  // namespace s4b
+#endif

@@ -1,0 +1,137 @@
+"""Parity of the HIP path (through the C-ABI, libs4b.so) against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): bit-exact for tree structure / indexing moves / RNG state / NUTS integer
+diagnostics, 1e-6 relative for leaf means, sigma, fits and HMC floating-point state.  NUTS trajectories
+amplify rounding differences by ~10x per Gibbs iteration on this posterior (hundreds of leapfrogs per
+transition), so joint (Stan + BART) chains are compared over the reference's own short test horizon
+(warmup 7 / iter 13, reference tests/testthat/test-05-rng.R:11-27) and the BART block alone over long runs.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_chain_parity, friedman_case, run_chain
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                   # BASELINE config 1 shape: n = 100, (1|g.1) + (1|g.2)
+    dict(T=50),
+    dict(ranef=False),
+    dict(slopes=True),
+    dict(n_test=17),
+    dict(stan_args={"hmc_mode": 1}),
+    dict(skip=(2, 1)),
+    dict(skip=(1, 3), warmup=3, iter=6),
+    dict(n=1003, T=50, warmup=10, iter=20),   # n not a multiple of 4: ragged tail of the vector loads
+    dict(n=7, T=3, warmup=2, iter=4, ranef=False),
+], ids=str)
+def test_hip_matches_oracle(oracle_lib, hip_lib, kw):
+    kw_o = {k: v for k, v in kw.items() if k != "stan_args"}
+    a = run_chain(oracle_lib, "orc_", friedman_case(**kw_o)[0])
+    b = run_chain(hip_lib, "s4b_", friedman_case(**kw)[0])
+    assert_chain_parity(a, b)
+    np.testing.assert_allclose(a["pm"], b["pm"], rtol=1e-6, atol=1e-9)
+
+
+def test_bart_block_long_run(oracle_lib, hip_lib):
+    args, _ = friedman_case(n=5000, T=40, warmup=30, iter=60)
+    a = run_chain(oracle_lib, "orc_", args, results_type=1)
+    b = run_chain(hip_lib, "s4b_", args, results_type=1)
+    assert len(a["trace"]) == 40 * 60 and set(np.unique(a["trace"][:, 0])) == {0, 1, 2, 3}
+    assert_chain_parity(a, b, stan=False)
+
+
+def test_config2_shape_fixed_effects_only(oracle_lib, hip_lib):
+    """BASELINE config 2 shape (n = 1e5, p = 10, 200 trees, fixed effects only), a few iterations."""
+    args, _ = friedman_case(n=100000, T=200, warmup=3, iter=6, ranef=False)
+    a = run_chain(oracle_lib, "orc_", args)
+    b = run_chain(hip_lib, "s4b_", args)
+    assert_chain_parity(a, b)
+
+
+def test_config3_shape_random_slopes_p50(oracle_lib, hip_lib):
+    """BASELINE config 3 shape at reduced n: p = 50 predictors, (1 + X4 | g.1) + (1 | g.2), 200 trees."""
+    args, _ = friedman_case(n=20000, p=50, T=200, warmup=2, iter=4, slopes=True)
+    a = run_chain(oracle_lib, "orc_", args)
+    b = run_chain(hip_lib, "s4b_", args)
+    assert_chain_parity(a, b)
+
+
+def test_user_offset_types(oracle_lib, hip_lib):
+    rng = np.random.default_rng(3)
+    for ot in ("default", "fixef", "ranef", "bart", "parametric"):
+        args, _ = friedman_case(offset=rng.normal(size=100), offset_type=ot, warmup=4, iter=8)
+        assert_chain_parity(run_chain(oracle_lib, "orc_", args), run_chain(hip_lib, "s4b_", args))
+
+
+def test_multi_pass_bins_and_deep_trees(oracle_lib, hip_lib):
+    args, _ = friedman_case(n=2000, T=4, warmup=20, iter=40, ranef=False, bart_args={"base": 0.99, "power": 0.45, "k": 0.5})
+    a = run_chain(oracle_lib, "orc_", args, results_type=1)
+    b = run_chain(hip_lib, "s4b_", args, results_type=1)
+    assert a["trace"][:, 4].max() > 16
+    assert_chain_parity(a, b, stan=False)
+
+
+def test_large_node_capacity_global_fallback(oracle_lib, hip_lib):
+    """node_capacity large enough that the control kernel cannot stage the tree in LDS (global-memory path)."""
+    args, _ = friedman_case(n=300, T=5, warmup=5, iter=10)
+    a = run_chain(oracle_lib, "orc_", args)
+    args.node_capacity = 4000
+    b = run_chain(hip_lib, "s4b_", args)
+    assert_chain_parity(a, b)
+
+
+def test_reproducible_run_to_run(hip_lib):
+    """reference tests/testthat/test-05-rng.R:29-44 on the device: same seed twice => bitwise identical draws
+    (all reductions have a fixed order)."""
+    args, _ = friedman_case(n=30000, T=50, warmup=5, iter=10)
+    a = run_chain(hip_lib, "s4b_", args)
+    b = run_chain(hip_lib, "s4b_", args)
+    assert np.array_equal(a["sample"]["bart"]["train"], b["sample"]["bart"]["train"])
+    assert np.array_equal(a["sample"]["stan"], b["sample"]["stan"])
+    assert np.array_equal(a["trace"], b["trace"])
+
+
+def test_keep_fits_false_and_callback(hip_lib):
+    seen = []
+    args, _ = friedman_case(keep_fits=False, callback=lambda tr, te, sp: seen.append((tr.copy(), sp.copy())))
+    r = run_chain(hip_lib, "s4b_", args)
+    assert len(seen) == 13 and r["sample"]["bart"]["train"].shape[1] == 1
+    np.testing.assert_array_equal(r["sample"]["bart"]["train"][:, 0], seen[-1][0])
+
+
+def test_size_independent_invariants_at_scale(hip_lib):
+    """n = 1e6, p = 50 (BASELINE config 3 size for one chain): properties that need no oracle —
+    every tree's leaf counts sum to n; test rows equal to training rows get identical fits; the fit returned
+    by run() equals the fit re-assembled from the flattened trees (sum of leaf values, un-rescaled)."""
+    n, n_test = 1_000_000, 64
+    args, d = friedman_case(n=n, p=50, T=20, warmup=2, iter=4, slopes=True, n_test=n_test)
+    r = run_chain(hip_lib, "s4b_", args, trace=False)
+    tr = r["trees"]
+    roots = np.r_[True, tr["tree"][1:] != tr["tree"][:-1]]
+    assert np.all(tr["n"][roots] == n)
+    leaf = tr["var"] < 0
+    for t in range(20):
+        m = (tr["tree"] == t) & leaf
+        assert tr["n"][m].sum() == n
+    np.testing.assert_allclose(r["sample"]["bart"]["test"][:, -1], r["sample"]["bart"]["train"][:n_test, -1], rtol=1e-9)
+    # re-assemble the last fit of observation 0..63 from the flattened trees
+    x = d["x"][:n_test][:, [j for j in range(50) if j != 3]]
+    lo, hi = r["range"]
+    fit = np.zeros(n_test)
+    for t in range(20):
+        idx = np.flatnonzero(tr["tree"] == t)
+        for i in range(n_test):
+            k = 0
+            while tr["var"][idx[k]] >= 0:
+                # preorder: left child is next; right child follows the whole left subtree
+                if x[i, tr["var"][idx[k]]] <= tr["value"][idx[k]]:
+                    k += 1
+                else:
+                    depth, k = 1, k + 1
+                    while depth > 0:
+                        depth += 1 if tr["var"][idx[k]] >= 0 else -1
+                        k += 1
+            fit[i] += tr["value"][idx[k]]
+    np.testing.assert_allclose((fit + 0.5) * (hi - lo) + lo, r["sample"]["bart"]["train"][:n_test, -1], rtol=1e-8, atol=1e-8)

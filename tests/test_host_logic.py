@@ -1,0 +1,135 @@
+"""Product host logic (Gibbs order, NUTS + tape gradient, propose/decide control code, C-ABI) run over a
+CPU emulation of the device layer (tests/emul, test infrastructure) and compared with the CPU oracle.
+Bit-exact on tree moves / indices / RNG state, 1e-6 relative on floating-point state.
+No GPU involved: the HIP kernels themselves are covered by tests/test_gpu_parity.py (-m gpu)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_chain_parity, friedman_case, run_chain
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                   # reference test setting: (1|g.1) + (1|g.2), warmup 7, iter 13, 11 trees
+    dict(ranef=False),                        # reference test-06-no_ranef.R
+    dict(slopes=True),                        # (1 + X4 | g.1) + (1 | g.2): BASELINE config 3 formula
+    dict(n_test=17),
+    dict(stan_args={"hmc_mode": 1}),          # per-leapfrog O(N) sums instead of sufficient statistics
+    dict(skip=(2, 1)),                        # n.thin = 2 BART sweeps per iteration
+    dict(skip=(1, 3), warmup=3, iter=6),      # 3 NUTS transitions per iteration (short: NUTS amplifies rounding)
+    dict(n=1000, T=50, warmup=10, iter=20),
+], ids=str)
+def test_emulated_product_matches_oracle(oracle_lib, emul_lib, kw):
+    kw = dict(kw)
+    if "stan_args" in kw:
+        args_o, _ = friedman_case(**{k: v for k, v in kw.items() if k != "stan_args"})
+    else:
+        args_o, _ = friedman_case(**kw)
+    args_e, _ = friedman_case(**kw)
+    a = run_chain(oracle_lib, "orc_", args_o)
+    b = run_chain(emul_lib, "emu_", args_e)
+    assert_chain_parity(a, b)
+    np.testing.assert_allclose(a["pm"], b["pm"], rtol=1e-6, atol=1e-9)
+
+
+def test_bart_only_long_run_matches_oracle(oracle_lib, emul_lib):
+    """results_type = 1 (BART only, reference src/init.cpp:821): thousands of tree updates stay identical."""
+    args, _ = friedman_case(n=500, T=30, warmup=40, iter=80)
+    a = run_chain(oracle_lib, "orc_", args, results_type=1)
+    b = run_chain(emul_lib, "emu_", args, results_type=1)
+    assert len(a["trace"]) == 30 * 80
+    assert set(np.unique(a["trace"][:, 0])) == {0, 1, 2, 3}
+    assert_chain_parity(a, b, stan=False)
+
+
+def test_user_offset_types(oracle_lib, emul_lib):
+    """offset_type in {default, fixef, ranef, bart, parametric} (reference src/init.cpp:83-97,762-795,831-839)."""
+    rng = np.random.default_rng(3)
+    for ot in ("default", "fixef", "ranef", "bart", "parametric"):
+        args, _ = friedman_case(offset=rng.normal(size=100), offset_type=ot, warmup=4, iter=8)
+        a = run_chain(oracle_lib, "orc_", args)
+        b = run_chain(emul_lib, "emu_", args)
+        assert_chain_parity(a, b)
+
+
+def test_keep_fits_false_and_callback(oracle_lib, emul_lib):
+    """reference tests/testthat/test-11-callback.R:76-99: keep_fits = FALSE keeps one slot; callback sees every draw."""
+    seen = {"o": [], "e": []}
+    for key, lib, pfx in (("o", oracle_lib, "orc_"), ("e", emul_lib, "emu_")):
+        args, _ = friedman_case(keep_fits=False, callback=lambda tr, te, sp, k=key: seen[k].append((tr.copy(), sp.copy())))
+        r = run_chain(lib, pfx, args)
+        assert r["sample"]["stan"].shape[1] == 1 and r["sample"]["bart"]["train"].shape[1] == 1
+        np.testing.assert_allclose(r["sample"]["bart"]["train"][:, 0], seen[key][-1][0], rtol=0, atol=0)
+    assert len(seen["o"]) == len(seen["e"]) == 13
+    for (t1, s1), (t2, s2) in zip(seen["o"], seen["e"]):
+        np.testing.assert_allclose(t1, t2, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(s1, s2, rtol=1e-6, atol=1e-9)
+
+
+def test_multi_pass_bins_and_deep_trees(oracle_lib, emul_lib):
+    """a flatter tree prior (base .99, power .45; still sub-critical) gives trees with > 16 leaves, the regime in
+    which the stats kernel needs several bin passes; the control code must agree with the oracle there as well."""
+    args, _ = friedman_case(n=2000, T=4, warmup=20, iter=40, ranef=False, bart_args={"base": 0.99, "power": 0.45, "k": 0.5})
+    a = run_chain(oracle_lib, "orc_", args, results_type=1)
+    b = run_chain(emul_lib, "emu_", args, results_type=1)
+    assert a["trace"][:, 4].max() > 16
+    assert_chain_parity(a, b, stan=False)
+
+
+def test_error_reporting(emul_lib):
+    """errors come back as status + message (the R shim raises them with Rf_error; reference src/init.cpp:319,681)."""
+    emul_lib.emu_last_error.restype = C.c_char_p
+    assert emul_lib.emu_run(None, 1, 0, 0, None) != 0
+    assert b"NULL sampler" in emul_lib.emu_last_error()
+    args, _ = friedman_case()
+    args.sigma_init = -1.0
+    with pytest.raises(RuntimeError, match="sigma_init"):
+        run_chain(emul_lib, "emu_", args)
+    args, _ = friedman_case(bart_args={"n.trees": 4})
+    args.node_capacity = 3
+    with pytest.raises(RuntimeError, match="node_capacity|node capacity"):
+        run_chain(emul_lib, "emu_", args)
+    args, _ = friedman_case()
+    args.is_binary = True
+    with pytest.raises(RuntimeError, match="binary"):
+        run_chain(emul_lib, "emu_", args)
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "stan4bart_amd.h")).read()
+    return sorted(set(re.findall(r"S4B_FN\((\w+)\)\s*\(", hdr)) - {"name"})
+
+
+def test_product_library_exports_every_declared_symbol(hip_lib):
+    """the C-ABI library loads on a CPU-only box and exports exactly what include/stan4bart_amd.h declares."""
+    names = _declared_symbols()
+    assert len(names) == 17
+    for n in names:
+        assert hasattr(hip_lib, "s4b_" + n), n
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "stan4bart_amd", "csrc", "libs4b.so")],
+                         stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = set(re.findall(r" T (s4b_\w+)", out))
+    assert exported == {"s4b_" + n for n in names}
+
+
+def test_product_has_no_cpu_fallback(hip_lib):
+    """without a HIP device the product must fail loudly, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    args, _ = friedman_case()
+    with pytest.raises(RuntimeError, match="no HIP device|HIP error"):
+        run_chain(hip_lib, "s4b_", args)
+
+
+def test_product_sources_do_not_reference_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "stan4bart_amd")):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".inc", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "liboracle" not in text and "oracle/" not in text and "import oracle" not in text, os.path.join(dirpath, f)
+                assert "libs4b_emul" not in text and "dev_cpu" not in text, os.path.join(dirpath, f)
