@@ -651,7 +651,7 @@ class DevHip {
     HIP_OK(hipHostMalloc(&pinned_, sizeof(double) * (size_t)(2 * (1 + K_ + q_) + 64), hipHostMallocDefault));
     if (nTest_) testOut_ = zalloc<double>((size_t)nTest_);
     // ---- launch configuration
-    gridN_ = (int)std::min<int64_t>(GRID_MAX, std::max<int64_t>(1, (n_ + BLOCK - 1) / BLOCK));
+    gridN_ = a.grid;   // one launch geometry for every O(N) kernel: the partial buffers are sized by it
     ldsStats_ = stats_lds_bytes(nc_); ldsApply_ = apply_lds_bytes(nc_); ldsControl_ = control_lds_bytes(nc_, P_);
     useLds_ = ldsControl_ <= 150 * 1024 ? 1 : 0;
     if (ldsStats_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsStats_));

@@ -23,7 +23,9 @@ pytestmark = pytest.mark.gpu
     dict(stan_args={"hmc_mode": 1}),
     dict(skip=(2, 1)),
     dict(skip=(1, 3), warmup=3, iter=6),
-    dict(n=1003, T=50, warmup=10, iter=20),   # n not a multiple of 4: ragged tail of the vector loads
+    dict(n=1003, T=50),                       # n not a multiple of 4: ragged tail of the vector loads
+    dict(n=1001, T=20, ranef=False, warmup=10, iter=20),
+    dict(n=1002, T=20, ranef=False),
     dict(n=7, T=3, warmup=2, iter=4, ranef=False),
 ], ids=str)
 def test_hip_matches_oracle(oracle_lib, hip_lib, kw):
@@ -34,8 +36,9 @@ def test_hip_matches_oracle(oracle_lib, hip_lib, kw):
     np.testing.assert_allclose(a["pm"], b["pm"], rtol=1e-6, atol=1e-9)
 
 
-def test_bart_block_long_run(oracle_lib, hip_lib):
-    args, _ = friedman_case(n=5000, T=40, warmup=30, iter=60)
+@pytest.mark.parametrize("n", [5000, 1003])
+def test_bart_block_long_run(oracle_lib, hip_lib, n):
+    args, _ = friedman_case(n=n, T=40, warmup=30, iter=60)
     a = run_chain(oracle_lib, "orc_", args, results_type=1)
     b = run_chain(hip_lib, "s4b_", args, results_type=1)
     assert len(a["trace"]) == 40 * 60 and set(np.unique(a["trace"][:, 0])) == {0, 1, 2, 3}
