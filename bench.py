@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Benchmark of the stan4bart Gibbs hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): Gibbs iterations / second at n = 1e6, p = 50, ntree = 200 — BASELINE config 3:
+Friedman data, formula y ~ bart(. - X4 - z - g.1 - g.2) + X4 + z + (1 + X4 | g.1) + (1 | g.2), one chain per GPU.
+A "step" is one Gibbs iteration = one NUTS transition of the Stan block + one BART sweep (200 tree updates).
+`value` is the whole-job aggregate over all N chains (chains are independent, so scaling is weak);
+`per_chain` is the BASELINE per-chain figure.  Inputs are resident in HBM before the timed region.
+
+Extra objects on the same JSON line:
+  roofline      dominant kernel of the sweep, HIP-event timing on the sampler's own stream, against 8 TB/s HBM
+  cpu_baseline  the CPU oracle (oracle/, "port") timed on this box's host, rank 0 at N = 1 only, on the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def build_case(n, p, trees, device, warmup, steps):
+    from stan4bart_amd import GroupTerm, generate_friedman_data, make_sampler_args
+    d = generate_friedman_data(n, ranef=True, causal=True, p=p)
+    x = d["x"]
+    xb = np.asfortranarray(x[:, [j for j in range(p) if j != 3]])
+    X = np.column_stack([x[:, 3], d["z"]])
+    groups = [GroupTerm(d["g1"], x[:, 3], "g.1"), GroupTerm(d["g2"], None, "g.2")]
+    args = make_sampler_args(d["y"], xb, X=X, groups=groups, iter=warmup + steps, warmup=warmup, keep_fits=False,
+                             bart_args={"n.trees": trees}, device=device)
+    return args
+
+
+def cpu_baseline(n, p, trees, iters):
+    """Time the CPU oracle (single thread, the reference's execution model: R/stan4bart_fit.R:437-439) on the
+    same workload for a bounded number of Gibbs iterations."""
+    import subprocess
+    from stan4bart_amd import RRng
+    from stan4bart_amd.abi import Sampler
+    so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    lib = ctypes.CDLL(so)
+    args = build_case(n, p, trees, 0, 0, iters)
+    rng = RRng(12345)
+    args.seed = int(rng.sample_int(2147483647, 1)[0])
+    s = Sampler(lib, "orc_", args, rng.state)
+    s.run(1, True, 0)                      # one untimed iteration (page-in)
+    t0 = time.perf_counter()
+    s.run(iters, True, 0)
+    dt = time.perf_counter() - t0
+    s.free()
+    return iters / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--p", type=int, default=50)
+    ap.add_argument("--trees", type=int, default=200)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-sweeps", type=int, default=2)
+    a = ap.parse_args()
+
+    import torch
+    from stan4bart_amd import RRng
+    from stan4bart_amd.abi import Sampler
+    from stan4bart_amd._lib import load_library
+    from stan4bart_amd.fit import chain_seeds
+    from stan4bart_amd.parallel import all_gather_array, init_process_group
+
+    rank, local_rank, world = init_process_group()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    lib = load_library()
+
+    args = build_case(a.n, a.p, a.trees, local_rank, a.warmup, a.steps)
+    rng = RRng(int(chain_seeds(20260101, max(1, world))[rank]))
+    args.seed = int(rng.sample_int(2147483647, 1)[0])
+    sampler = Sampler(lib, "s4b_", args, rng.state)     # uploads everything: inputs are HBM-resident from here on
+    if a.warmup > 0:
+        sampler.run(a.warmup, True, 0)                  # W untimed warm-up Gibbs iterations (adaptation engaged)
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    c0 = sampler.get_counters()
+    t0 = time.perf_counter()
+    out = sampler.run(a.steps, True, 0)                 # exactly K timed Gibbs iterations (run() returns synchronised)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c1 = sampler.get_counters()
+    barrier()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt_max = float(t.item())
+    else:
+        dt_max = dt
+    sig = all_gather_array(np.array([float(out["bart"]["sigma"][-1])]))   # the only collective: chain summaries
+
+    prof = sampler.profile_sweep(a.profile_sweeps) if rank == 0 else None
+    sampler.free()
+
+    if rank == 0:
+        n = a.n
+        per_chain = a.steps / dt_max
+        # dominant kernel of the sweep and its algorithmic bytes per launch (DESIGN.md "Roofline accounting")
+        kernels = {"k_apply": (prof["apply_us"], 18.0 * n), "k_stats": (prof["stats_us"], 10.0 * n)}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        dom_us, dom_bytes = kernels[dom]
+        achieved = dom_bytes / (dom_us * 1e-6) / 1e9
+        tree_update_us = prof["stats_us"] + prof["control_us"] + prof["apply_us"]
+        rec = {
+            "metric": "gibbs_iters_per_sec", "value": per_chain * world, "unit": "Gibbs iterations/s (all chains)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt_max / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "per_chain": per_chain,
+            "config": {"workload": f"Friedman n={n}, p={a.p}, ntree={a.trees}, (1+X4|g.1)+(1|g.2), one chain per GPU (BASELINE config 3)",
+                       "chains": world, "hmc_mode": "sufficient-statistics", "n_leapfrog_timed": int(c1[0] - c0[0]),
+                       "tree_updates_timed": int(c1[1] - c0[1]), "sigma_last": [float(s[0]) for s in sig]},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
+                         "tree_update": {"stats_us": prof["stats_us"], "control_us": prof["control_us"], "apply_us": prof["apply_us"],
+                                         "algorithmic_bytes": 22.0 * n,
+                                         "achieved_GBs_over_all_three": 22.0 * n / (tree_update_us * 1e-6) / 1e9},
+                         "sweep_wall_us": prof["sweep_wall_us"]},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            v, secs = cpu_baseline(a.n, a.p, a.trees, a.cpu_iters)
+            rec["cpu_baseline"] = {"value": v, "unit": "Gibbs iterations/s/chain", "cores": 1, "kind": "port",
+                                   "sample": f"same workload (n={n}, p={a.p}, ntree={a.trees}), {a.cpu_iters} Gibbs iterations, "
+                                             f"{secs:.1f} s of single-thread CPU time, host has {os.cpu_count()} cores"}
+        print(json.dumps(rec))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

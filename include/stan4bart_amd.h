@@ -179,6 +179,12 @@ int S4B_FN(get_leaf_assignment)(s4b_sampler* s, int32_t tree, int32_t* out);
 /* counters: {log-density gradient evaluations, tree updates, device kernel launches} */
 int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
 
+/* measurement hook (no reference counterpart): runs `n_sweeps` extra BART sweeps with HIP events recorded on the
+ * sampler's own stream around every kernel launch and returns, per kernel class
+ * {stats, control, apply}: out[0..2] = average launch duration in microseconds, out[3..5] = launches timed,
+ * out[6] = wall microseconds per sweep (events around the whole sweep, no per-launch events), out[7] = n. */
+int S4B_FN(profile_sweep)(s4b_sampler* s, int32_t n_sweeps, double out[8]);
+
 /* finalizer of the externalptr — src/init.cpp:1152-1165 */
 void S4B_FN(free)(s4b_sampler* s);
 

@@ -279,6 +279,7 @@ int orc_get_leaf_assignment(s4b_sampler* s, int32_t t, int32_t* out) {
 }
 int orc_get_counters(s4b_sampler* s, int64_t out[3]) { out[0] = s->model->gradEvals; out[1] = s->treeUpdates; out[2] = 0; return 0; }
 
+int orc_profile_sweep(s4b_sampler*, int32_t, double out[8]) { for (int i = 0; i < 8; ++i) out[i] = 0.0; return 0; }
 void orc_free(s4b_sampler* s) { delete s; }
 
 // ---- small extras used only by tests: direct access to the RNG restatements and the model ----

@@ -243,7 +243,7 @@ class Sampler:
     def _bind(self):
         for name in ("create", "run", "disengage_adaptation", "print_initial_summary", "get_parametric_mean",
                      "get_bart_data_range", "get_r_rng_state", "set_r_rng_state", "get_dims", "get_stan_par_names",
-                     "get_trees", "set_trace", "get_trace", "get_leaf_assignment", "get_counters"):
+                     "get_trees", "set_trace", "get_trace", "get_leaf_assignment", "get_counters", "profile_sweep"):
             getattr(self._lib, self._pfx + name).restype = C.c_int
         getattr(self._lib, self._pfx + "last_error").restype = C.c_char_p
         getattr(self._lib, self._pfx + "free").restype = None
@@ -343,6 +343,13 @@ class Sampler:
         out = (C.c_int64 * 3)()
         self._check(self._f("get_counters")(self._h, out))
         return np.array(list(out), dtype=np.int64)
+
+    def profile_sweep(self, n_sweeps: int = 1) -> dict:
+        """Extra BART sweeps timed with HIP events on the sampler's stream (measurement hook of the HIP library)."""
+        out = (C.c_double * 8)()
+        self._check(self._f("profile_sweep")(self._h, n_sweeps, out))
+        return dict(stats_us=out[0], control_us=out[1], apply_us=out[2], launches=[out[3], out[4], out[5]],
+                    sweep_wall_us=out[6], n=int(out[7]))
 
     def free(self):
         if getattr(self, "_h", None) and self._h.value:

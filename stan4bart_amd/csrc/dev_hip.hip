@@ -728,6 +728,43 @@ class DevHip {
       }
     }
   }
+  // per-launch HIP-event timing of extra sweeps on the sampler's stream (bench.py roofline leg)
+  void profile_sweep(int nSweeps, int thin, double* out) {
+    const int perSweep = 3 * T_ * thin;
+    std::vector<hipEvent_t> ev((size_t)perSweep * 2);
+    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+    double sum[3] = {0, 0, 0}, cnt[3] = {0, 0, 0};
+    const size_t ldsC = useLds_ ? ldsControl_ : 0;
+    for (int sIdx = 0; sIdx < nSweeps; ++sIdx) {
+      size_t e = 0;
+      for (int k = 0; k < thin; ++k) {
+        hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsC, stream_, a_, -1, 0, useLds_); ++launches_;
+        for (int t = 0; t < T_; ++t) {
+          HIP_OK(hipEventRecord(ev[e++], stream_));
+          hipLaunchKernelGGL(k_stats, dim3(a_.grid), dim3(BLOCK), ldsStats_, stream_, a_, t);
+          HIP_OK(hipEventRecord(ev[e++], stream_));
+          HIP_OK(hipEventRecord(ev[e++], stream_));
+          hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsC, stream_, a_, t, t + 1 < T_ ? t + 1 : -1, useLds_);
+          HIP_OK(hipEventRecord(ev[e++], stream_));
+          HIP_OK(hipEventRecord(ev[e++], stream_));
+          hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, t);
+          HIP_OK(hipEventRecord(ev[e++], stream_));
+          launches_ += 3;
+        }
+      }
+      sync();
+      for (size_t i = 0; i + 1 < e; i += 2) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); int c = (int)((i / 2) % 3); sum[c] += ms * 1000.0; cnt[c] += 1; }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    for (int c = 0; c < 3; ++c) { out[c] = cnt[c] ? sum[c] / cnt[c] : 0.0; out[3 + c] = cnt[c]; }
+    // wall time per sweep without per-launch events
+    HIP_OK(hipEventRecord(evStart_, stream_));
+    for (int sIdx = 0; sIdx < nSweeps; ++sIdx) sweep(thin);
+    HIP_OK(hipEventRecord(evStop_, stream_));
+    sync();
+    float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_));
+    out[6] = ms * 1000.0 / nSweeps;
+  }
   void test_fits(double* out) {
     int g = (int)std::min<int64_t>(GRID_MAX, std::max<int64_t>(1, (nTest_ + BLOCK - 1) / BLOCK));
     hipLaunchKernelGGL(k_test_fits, dim3(g), dim3(BLOCK), 0, stream_, a_, testOut_); ++launches_;

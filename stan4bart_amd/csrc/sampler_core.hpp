@@ -251,6 +251,7 @@ class SamplerCore {
     dev_.download_leaf_plane(t, leaf.data());
     for (size_t i = 0; i < n_; ++i) out[i] = rank[leaf[i]];
   }
+  void profile_sweep(int nSweeps, double out[8]) { if (nSweeps < 1) throw std::invalid_argument("n_sweeps must be >= 1"); dev_.profile_sweep(nSweeps, thin_, out); out[7] = (double)n_; check_device(); }
   void counters(int64_t out[3]) { out[0] = model_->gradEvals; out[1] = treeUpdates_; out[2] = dev_.launches(); }
   Dev& dev() { return dev_; }
 

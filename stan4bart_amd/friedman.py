@@ -26,11 +26,11 @@ def generate_friedman_data(n: int, ranef: bool = False, causal: bool = False, bi
 
     res = dict(x=x, sigma=sigma, mu_bart=f(x), mu_fixef=x[:, 3] * 10)
     if ranef:
-        g1 = rng.sample_int(n_g1, n) if n <= 200000 else _fast_sample(rng, n_g1, n)
+        g1 = rng.sample_int(n_g1, n) if n <= 2000 else _fast_sample(rng, n_g1, n)
         Sigma_b1 = np.array([[1.5 ** 2, 0.2], [0.2, 1.0]])
         R_b = np.linalg.cholesky(Sigma_b1).T
         b1 = rng.rnorm(2 * n_g1).reshape((n_g1, 2), order="F") @ R_b
-        g2 = rng.sample_int(n_g2, n) if n <= 200000 else _fast_sample(rng, n_g2, n)
+        g2 = rng.sample_int(n_g2, n) if n <= 2000 else _fast_sample(rng, n_g2, n)
         b2 = rng.rnorm(n_g2, 0.0, np.sqrt(1.2))
         res.update(g1=g1, g2=g2, b1=b1, b2=b2)
         res["mu_ranef"] = b1[g1 - 1, 0] + x[:, 3] * b1[g1 - 1, 1] + b2[g2 - 1]

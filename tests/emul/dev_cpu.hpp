@@ -153,6 +153,7 @@ class DevCpu {
       }
     }
   }
+  void profile_sweep(int nSweeps, int thin, double* out) { for (int i = 0; i < 8; ++i) out[i] = 0.0; for (int k = 0; k < nSweeps; ++k) sweep(thin); }
   void test_fits(double* out) {
     for (size_t i = 0; i < nTest_; ++i) {
       double f = 0.0;
