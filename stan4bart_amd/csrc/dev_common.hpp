@@ -22,6 +22,8 @@ struct StepScratch {
   int16_t *pvar, *pleft, *pright, *pparent; uint16_t* pcut;
   int16_t *binA, *binB, *list; uint8_t* insub;
   double* muOld; Proposal* prop; int32_t* accepted;
+  int16_t *cna, *cdep, *pna, *pdep;   // node memos of the current / proposed tree (pointer path)
+  double* work;                       // [6][2 nc] decide() work arrays (pointer path)
 };
 
 // device-resident state of one chain's BART block (all pointers are device pointers)
@@ -54,58 +56,46 @@ struct BartArrays {
 };
 
 S4B_HD inline TreeView tree_view(const BartArrays& a, int t) {
-  TreeView v; size_t o = (size_t)t * (size_t)a.nc;
-  v.var = a.var + o; v.cut = a.cut + o; v.left = a.left + o; v.right = a.right + o; v.parent = a.parent + o; v.nc = a.nc;
-  return v;
+  size_t o = (size_t)t * (size_t)a.nc;
+  const StepScratch& c = a.sc[t & 1];
+  return make_tree_view(a.var + o, a.cut + o, a.left + o, a.right + o, a.parent + o, a.nc, c.cna, c.cdep);
 }
 S4B_HD inline StepTables step_tables(const BartArrays& a, int t) {
   const StepScratch& c = a.sc[t & 1];
   StepTables s;
-  s.prop.var = c.pvar; s.prop.cut = c.pcut; s.prop.left = c.pleft; s.prop.right = c.pright; s.prop.parent = c.pparent; s.prop.nc = a.nc;
-  s.binA = c.binA; s.binB = c.binB; s.insub = c.insub; s.list = c.list;
+  s.prop = make_tree_view(c.pvar, c.pcut, c.pleft, c.pright, c.pparent, a.nc, c.pna, c.pdep);
+  s.binA = PtrArr<int16_t>(c.binA); s.binB = PtrArr<int16_t>(c.binB); s.insub = PtrArr<uint8_t>(c.insub); s.list = PtrArr<int16_t>(c.list);
   return s;
 }
 
-// explicit view of everything one tree update's control code touches (may point to global memory or
-// to LDS-staged copies inside the control kernel)
-struct StepCtx {
-  TreeView cur; double* mu; int32_t* cnt; int32_t hwm;
-  StepTables tb; double* muOld; Proposal* prop; int32_t* accepted;
-};
-
-S4B_HD inline StepCtx step_ctx(const BartArrays& a, int t) {
-  StepCtx c; const StepScratch& s = a.sc[t & 1];
-  c.cur = tree_view(a, t); c.mu = a.mu + (size_t)t * a.nc; c.cnt = a.cnt + (size_t)t * a.nc; c.hwm = a.hwm[t];
-  c.tb = step_tables(a, t); c.muOld = s.muOld; c.prop = s.prop; c.accepted = s.accepted;
-  return c;
-}
-
-// draw the proposal for the tree behind `c` (structure only)
-S4B_HD inline void ctx_propose(StepCtx& c, const ModelView& m, MTState* rng, int32_t* errFlag) {
-  if (propose(c.cur, c.hwm, m, rng, c.prop, c.tb) != 0) *errFlag |= S4B_ERR_NODE_CAPACITY;
-}
-
-// consume the reduced bins of the pending proposal: accept/reject, leaf draws; updates c.hwm
-S4B_HD inline void ctx_decide(StepCtx& c, const ModelView& m, double sigma, MTState* rng, const double* binCnt, const double* binSum,
-                              StepRecord* rec) {
-  c.hwm = decide(c.cur, c.mu, c.cnt, c.muOld, c.hwm, m, sigma, rng, c.prop, c.tb, binCnt, binSum, c.accepted, rec);
-}
-
-// the same two steps straight on the global arrays (host emulation; also the fallback when a tree is too
-// large to stage)
+// the control steps straight on the global arrays (host emulation of the device layer; also the device
+// fallback when a tree has more node slots than the wave-register path handles)
 S4B_HD inline void propose_step(const BartArrays& a, int t) {
-  StepCtx c = step_ctx(a, t);
-  ctx_propose(c, a.model, a.rng, a.errFlag);
+  TreeView cur = tree_view(a, t);
+  StepTables tb = step_tables(a, t);
+  const int hwm = a.hwm[t];
+  tv_fill_info(cur, a.model, 0);
+  tv_copy(cur, tb.prop, hwm);
+  for (int i = 0; i < hwm; ++i) { tb.binA.set(i, -1); tb.binB.set(i, -1); tb.insub.set(i, 0); }
+  if (propose(cur, hwm, a.model, a.rng, a.sc[t & 1].prop, tb) != 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
 }
 S4B_HD inline void push_trace(const BartArrays& a, const StepRecord& rec) {
   int k = *a.traceCount;
   if (k < a.traceCap) { a.trace[k] = rec; *a.traceCount = k + 1; } else *a.errFlag |= S4B_ERR_TRACE_OVERFLOW;
 }
 S4B_HD inline void control_step(const BartArrays& a, int t, int proposeNext) {
-  StepCtx c = step_ctx(a, t);
+  TreeView cur = tree_view(a, t);
+  StepTables tb = step_tables(a, t);
+  const StepScratch& c = a.sc[t & 1];
+  PtrArr<double> mu(a.mu + (size_t)t * a.nc), muOld(c.muOld), binCnt(a.binCnt), binSum(a.binSum);
+  PtrArr<int32_t> cnt(a.cnt + (size_t)t * a.nc);
+  DecideWork<PtrArr<double>> wk;
+  const size_t ws = (size_t)2 * a.nc;
+  wk.ll = PtrArr<double>(c.work); wk.lc = PtrArr<double>(c.work + ws); wk.ls = PtrArr<double>(c.work + 2 * ws);
+  wk.u1 = PtrArr<double>(c.work + 3 * ws); wk.u2 = PtrArr<double>(c.work + 4 * ws); wk.val = PtrArr<double>(c.work + 5 * ws);
   StepRecord rec;
-  ctx_decide(c, a.model, a.scale->sigma, a.rng, a.binCnt, a.binSum, a.traceOn ? &rec : nullptr);
-  a.hwm[t] = c.hwm;
+  a.hwm[t] = decide(cur, mu, cnt, muOld, a.hwm[t], a.model, a.scale->sigma, a.rng, c.prop, tb, binCnt, binSum, wk, c.accepted,
+                    a.traceOn ? &rec : nullptr);
   if (a.traceOn) push_trace(a, rec);
   if (proposeNext >= 0) propose_step(a, proposeNext);
 }

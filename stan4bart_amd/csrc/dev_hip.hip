@@ -33,7 +33,7 @@ namespace s4b {
   } while (0)
 
 constexpr int BLOCK = 256;          // 4 waves
-constexpr int GRID_MAX = 1024;      // workgroups of the O(N) kernels (4 per CU)
+constexpr int GRID_MAX = 512;       // workgroups of the O(N) kernels (2 per CU); also the number of partials per bin
 constexpr int NBMAX = 16;           // bins accumulated in registers per pass
 
 // ------------------------------------------------------------------------------------------------
@@ -155,73 +155,108 @@ __global__ __launch_bounds__(BLOCK) void k_stats(BartArrays a, int t) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_control: combines the per-workgroup partials in a fixed order, then lane 0 runs the Metropolis-Hastings
-// control code (decide tree t, draw its leaves, draw the proposal of the next tree) on LDS-staged copies.
-struct ControlLds {
-  // staged arrays for the tree being decided (cur) and, optionally, the next tree to propose
-  int16_t *var, *left, *right, *parent; uint16_t* cut; double* mu; int32_t* cnt;
-  int16_t *pvar, *pleft, *pright, *pparent; uint16_t* pcut; int16_t *binA, *binB, *list; uint8_t* insub; double* muOld;
+// k_control: combines the per-workgroup partials in a fixed order, then wave 0 runs the Metropolis-Hastings
+// control code for tree t (decide + leaf draws) and draws the proposal of tree `next`.
+//
+// The control code is sequential and branchy; run from memory (even LDS) every dependent access costs
+// 64+ cycles.  Here every small array of the step (tree structure, proposed tree, bin maps, leaf values) is
+// held in ONE VGPR spread across the 64 lanes of the wave — element i lives in lane i — and read with
+// v_readlane / written with v_writelane.  All 64 lanes execute the same (wave-uniform) scalar program, so an
+// "array access" is a 1-instruction register access.  Trees with more than 64 node slots in use take the
+// slower global-memory path (same source, pointer storage).
+template <class T>
+struct WaveArr {   // up to 64 elements of an integer type of <= 32 bits
+  int r;
+  __device__ __forceinline__ T get(int i) const { return (T)__builtin_amdgcn_readlane(r, i); }
+  __device__ __forceinline__ void set(int i, T v) { r = ((int)(threadIdx.x & 63) == i) ? (int)v : r; }
 };
-static size_t control_lds_bytes(int nc, int P) {
-  // two tree images (decided tree + next tree): 5 x 2 B structure, mu 8, cnt 4, proposal tables 8 x 2 + 1, muOld 8
-  size_t per = (size_t)nc * (10 + 8 + 4 + 16 + 1 + 8) + 17 * 16 + 2 * sizeof(Proposal);
-  return 2 * per + (size_t)2 * nc * 16 /*bins*/ + sizeof(MTState) + (size_t)P * 4 + 512;
-}
-
-__device__ __forceinline__ unsigned char* carve(unsigned char*& p, size_t bytes) {
-  unsigned char* r = p; p += (bytes + 15) / 16 * 16; return r;
-}
-
-__device__ void stage_tree(int nc, const StepCtx& g, StepCtx& l, unsigned char*& p) {
-  // g: context on the global arrays, l: the same shapes carved out of LDS
-  l = g;
-  l.cur.var = (int16_t*)carve(p, (size_t)nc * 2); l.cur.cut = (uint16_t*)carve(p, (size_t)nc * 2);
-  l.cur.left = (int16_t*)carve(p, (size_t)nc * 2); l.cur.right = (int16_t*)carve(p, (size_t)nc * 2);
-  l.cur.parent = (int16_t*)carve(p, (size_t)nc * 2);
-  l.mu = (double*)carve(p, (size_t)nc * 8); l.cnt = (int32_t*)carve(p, (size_t)nc * 4);
-  l.tb.prop.var = (int16_t*)carve(p, (size_t)nc * 2); l.tb.prop.cut = (uint16_t*)carve(p, (size_t)nc * 2);
-  l.tb.prop.left = (int16_t*)carve(p, (size_t)nc * 2); l.tb.prop.right = (int16_t*)carve(p, (size_t)nc * 2);
-  l.tb.prop.parent = (int16_t*)carve(p, (size_t)nc * 2);
-  l.tb.binA = (int16_t*)carve(p, (size_t)nc * 2); l.tb.binB = (int16_t*)carve(p, (size_t)nc * 2);
-  l.tb.list = (int16_t*)carve(p, (size_t)nc * 2); l.tb.insub = (uint8_t*)carve(p, (size_t)nc);
-  l.muOld = (double*)carve(p, (size_t)nc * 8);
-  l.prop = (Proposal*)carve(p, sizeof(Proposal));
-}
-
-__device__ void copy_tree_in(const StepCtx& g, StepCtx& l, int count, bool withTables) {
-  for (int i = threadIdx.x; i < count; i += blockDim.x) {
-    l.cur.var[i] = g.cur.var[i]; l.cur.cut[i] = g.cur.cut[i]; l.cur.left[i] = g.cur.left[i]; l.cur.right[i] = g.cur.right[i];
-    l.cur.parent[i] = g.cur.parent[i]; l.mu[i] = g.mu[i]; l.cnt[i] = g.cnt[i];
-    if (withTables) {
-      l.tb.prop.var[i] = g.tb.prop.var[i]; l.tb.prop.cut[i] = g.tb.prop.cut[i]; l.tb.prop.left[i] = g.tb.prop.left[i];
-      l.tb.prop.right[i] = g.tb.prop.right[i]; l.tb.prop.parent[i] = g.tb.prop.parent[i];
-      l.tb.binA[i] = g.tb.binA[i]; l.tb.binB[i] = g.tb.binB[i]; l.tb.insub[i] = g.tb.insub[i];
-    }
+struct WaveArrD {  // up to 64 doubles
+  int lo, hi;
+  __device__ __forceinline__ double get(int i) const {
+    return __hiloint2double(__builtin_amdgcn_readlane(hi, i), __builtin_amdgcn_readlane(lo, i));
   }
-}
-__device__ void copy_tree_out(const StepCtx& l, StepCtx& g, int count, bool curAndMu, bool tables) {
-  for (int i = threadIdx.x; i < count; i += blockDim.x) {
-    if (curAndMu) {
-      g.cur.var[i] = l.cur.var[i]; g.cur.cut[i] = l.cur.cut[i]; g.cur.left[i] = l.cur.left[i]; g.cur.right[i] = l.cur.right[i];
-      g.cur.parent[i] = l.cur.parent[i]; g.mu[i] = l.mu[i]; g.cnt[i] = l.cnt[i]; g.muOld[i] = l.muOld[i]; g.tb.insub[i] = l.tb.insub[i];
-    }
-    if (tables) {
-      g.tb.prop.var[i] = l.tb.prop.var[i]; g.tb.prop.cut[i] = l.tb.prop.cut[i]; g.tb.prop.left[i] = l.tb.prop.left[i];
-      g.tb.prop.right[i] = l.tb.prop.right[i]; g.tb.prop.parent[i] = l.tb.prop.parent[i];
-      g.tb.binA[i] = l.tb.binA[i]; g.tb.binB[i] = l.tb.binB[i]; g.tb.insub[i] = l.tb.insub[i];
-    }
+  __device__ __forceinline__ void set(int i, double v) {
+    const bool me = (int)(threadIdx.x & 63) == i;
+    lo = me ? __double2loint(v) : lo;
+    hi = me ? __double2hiint(v) : hi;
   }
+  __device__ __forceinline__ void load(double v) { lo = __double2loint(v); hi = __double2hiint(v); }
+  __device__ __forceinline__ double mine() const { return __hiloint2double(hi, lo); }
+};
+typedef TreeT<WaveArr<int16_t>, WaveArr<uint16_t>> WaveTree;
+typedef StepTablesT<WaveTree, WaveArr<int16_t>, WaveArr<uint8_t>> WaveTables;
+
+// whole-register copy (overload picked over the element-wise template)
+__device__ __forceinline__ void tv_copy(const WaveTree& src, WaveTree& dst, int) {
+  dst.var.r = src.var.r; dst.cut.r = src.cut.r; dst.left.r = src.left.r; dst.right.r = src.right.r; dst.parent.r = src.parent.r;
+  dst.na.r = src.na.r; dst.dep.r = src.dep.r;
+}
+// lane-parallel versions of the batched math of decide(): lane b / lane i owns bin b / leaf i
+__device__ __forceinline__ void bins_loglik(const WaveArrD& binCnt, const WaveArrD& binSum, int, double sigma2, double prec, WaveArrD& out) {
+  const double c = binCnt.mine();
+  out.load(c == 0.0 ? 0.0 : leaf_loglik(c, binSum.mine(), sigma2, prec));
+}
+__device__ __forceinline__ void leaves_draw(const WaveArrD& lc, const WaveArrD& ls, const WaveArrD& u1, const WaveArrD& u2, int nl, double sigma2,
+                                            double prec, WaveArrD& out) {
+  const double c = lc.mine();
+  double v = 0.0;
+  if ((int)(threadIdx.x & 63) < nl && c != 0.0) {
+    const double BIG = 134217728.0;
+    const double z = r_qnorm(((double)(int)(BIG * u1.mine()) + u2.mine()) / BIG);
+    const double postPrec = c / sigma2;
+    const double mean = postPrec * (ls.mine() / c) / (prec + postPrec);
+    const double sd = 1.0 / sqrt(prec + postPrec);
+    v = mean + sd * z;
+  }
+  out.load(v);
 }
 
-// mode: bit0 = decide tree t (requires reduced partials), bit1 = propose tree `next`
-__global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next, int useLds) {
+__device__ __forceinline__ void wave_tree_load(WaveTree& t, const int16_t* var, const uint16_t* cut, const int16_t* left, const int16_t* right,
+                                               const int16_t* parent, int count, int nc, int lane) {
+  const bool in = lane < count;
+  t.var.r = in ? (int)var[lane] : (int)NODE_FREE; t.cut.r = in ? (int)cut[lane] : 0; t.left.r = in ? (int)left[lane] : -1;
+  t.right.r = in ? (int)right[lane] : -1; t.parent.r = in ? (int)parent[lane] : -1; t.na.r = 0; t.dep.r = 0; t.nc = nc < 64 ? nc : 64;
+}
+__device__ __forceinline__ void wave_tree_store(const WaveTree& t, int16_t* var, uint16_t* cut, int16_t* left, int16_t* right, int16_t* parent,
+                                                int count, int lane) {
+  if (lane < count) { var[lane] = (int16_t)t.var.r; cut[lane] = (uint16_t)t.cut.r; left[lane] = (int16_t)t.left.r; right[lane] = (int16_t)t.right.r;
+                      parent[lane] = (int16_t)t.parent.r; }
+}
+
+#ifdef S4B_CONTROL_TIMING
+__device__ long long g_dbg[8];
+#define S4B_TICK(x) long long x = wall_clock64()
+#else
+#define S4B_TICK(x)
+#endif
+// slow path for trees with more than 64 node slots in use: the sequential code straight on the global arrays
+__device__ __attribute__((noinline)) void control_global_path(BartArrays a, int t, int next, double* scratch) {
+  a.model.scratch = scratch;
+  if (t >= 0) control_step(a, t, next); else propose_step(a, next);
+}
+
+static size_t control_lds_bytes(int P, int logIntLen) { return ((size_t)P * 4 + 15) / 16 * 16 + (size_t)logIntLen * 8 + 64; }
+
+__global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ MTState s_rng;
+  __shared__ double s_tab[3 * S4B_MAX_DEPTH];
+  __shared__ double s_scratch[S4B_MAX_DEPTH];
+  __shared__ double s_red[2][BLOCK / 64][64];
+  __shared__ Proposal s_prT, s_prN;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  S4B_TICK(c0);
   const bool doDecide = t >= 0;
-  if (!useLds) {   // tree too large to stage: run straight on the global arrays
+  const StepScratch& cT = a.sc[(doDecide ? t : 0) & 1];
+  const StepScratch& cN = a.sc[(next >= 0 ? next : 0) & 1];
+  // every thread derives the path from the same few words (no flag, no extra barrier)
+  int need = 0, nb = 0, hwmT = 0, hwmN = 0;
+  Proposal prT;
+  if (doDecide) { prT = *cT.prop; hwmT = a.hwm[t]; need = prT.hwm > hwmT ? prT.hwm : hwmT; nb = prT.nbA + prT.nbB; }
+  if (next >= 0) { hwmN = a.hwm[next]; if (hwmN + 2 > need) need = hwmN + 2; }
+  const bool wavePath = need <= 64 && nb <= 64;
+  if (!wavePath) {   // large tree: sequential code straight on the global arrays
     if (doDecide) {
-      const Proposal* pr = a.sc[t & 1].prop;
-      const int nb = pr->nbA + pr->nbB;
       for (int k = wv; k < nb; k += BLOCK / 64) {
         double s = 0.0, c = 0.0;
         for (int b = lane; b < a.grid; b += 64) { s += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
@@ -231,61 +266,87 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
       __threadfence();
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      if (doDecide) control_step(a, t, next); else propose_step(a, next);
-    }
+    if (threadIdx.x == 0) control_global_path(a, t, next, s_scratch);
     return;
   }
-  unsigned char* p = smem;
-  double* binSum = (double*)carve(p, (size_t)2 * a.nc * 8);
-  double* binCnt = (double*)carve(p, (size_t)2 * a.nc * 8);
-  MTState* rng = (MTState*)carve(p, sizeof(MTState));
-  int32_t* numCuts = (int32_t*)carve(p, (size_t)a.P * 4);
-  int32_t* s_hwm = (int32_t*)carve(p, 16);   // [0] entries to write back for tree t, [1] for tree `next`
-  StepCtx gT, lT, gN, lN;
-  if (doDecide) { gT = step_ctx(a, t); stage_tree(a.nc, gT, lT, p); }
-  if (next >= 0) { gN = step_ctx(a, next); stage_tree(a.nc, gN, lN, p); }
-  // ---- stage in
-  for (int i = threadIdx.x; i < (int)(sizeof(MTState) / 4); i += BLOCK) ((uint32_t*)rng)[i] = ((const uint32_t*)a.rng)[i];
+  // ---- stage the small shared state into LDS; all 256 threads cooperate on every bin's partials
+  int32_t* numCuts = (int32_t*)smem;
+  double* logInt = (double*)(smem + ((size_t)a.P * 4 + 15) / 16 * 16);
+  for (int i = threadIdx.x; i < (int)(sizeof(MTState) / 4); i += BLOCK) ((uint32_t*)&s_rng)[i] = ((const uint32_t*)a.rng)[i];
   for (int i = threadIdx.x; i < a.P; i += BLOCK) numCuts[i] = a.numCuts[i];
+  for (int i = threadIdx.x; i < a.model.logIntLen; i += BLOCK) logInt[i] = a.model.logInt[i];
+  for (int i = threadIdx.x; i < S4B_MAX_DEPTH; i += BLOCK) {
+    s_tab[i] = a.model.pgDepth[i]; s_tab[S4B_MAX_DEPTH + i] = a.model.logPg[i]; s_tab[2 * S4B_MAX_DEPTH + i] = a.model.log1mPg[i];
+  }
   if (doDecide) {
-    if (threadIdx.x == 0) *lT.prop = *gT.prop;
-    __syncthreads();
-    const int cnt = lT.prop->hwm;   // proposal tables are valid up to the proposal's hwm (>= tree hwm)
-    copy_tree_in(gT, lT, cnt, true);
-    const int nb = lT.prop->nbA + lT.prop->nbB;
-    for (int k = wv; k < nb; k += BLOCK / 64) {
-      double s = 0.0, c = 0.0;
-      for (int b = lane; b < a.grid; b += 64) { s += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
-      s = wave_sum(s); c = wave_sum(c);
-      if (lane == 0) { binSum[k] = s; binCnt[k] = c; }
+    for (int k0 = 0; k0 < nb; k0 += 8) {   // all loads of a batch of 8 bins are issued before any reduction
+      double s[8], c[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] = 0.0; c[j] = 0.0; }
+      for (int b = threadIdx.x; b < a.grid; b += BLOCK) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (k0 + j < nb) { s[j] += a.partSum[(size_t)(k0 + j) * a.grid + b]; c[j] += a.partCnt[(size_t)(k0 + j) * a.grid + b]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (k0 + j < nb) {
+        const double ss = wave_sum(s[j]), cc = wave_sum(c[j]);
+        if (lane == 0) { s_red[0][wv][k0 + j] = ss; s_red[1][wv][k0 + j] = cc; }
+      }
     }
+    if (threadIdx.x == 0) s_prT = prT;
   }
-  if (next >= 0) copy_tree_in(gN, lN, gN.hwm, false);
   __syncthreads();
-  // ---- one lane: the sequential Metropolis-Hastings control code
-  if (threadIdx.x == 0) {
-    ModelView m = a.model; m.numCuts = numCuts;
-    if (doDecide) {
-      StepRecord rec;
-      lT.hwm = gT.hwm;
-      ctx_decide(lT, m, a.scale->sigma, rng, binCnt, binSum, a.traceOn ? &rec : nullptr);
-      a.hwm[t] = lT.hwm;
+  if (wv != 0) return;
+  S4B_TICK(c1);
+  // ---- wave 0: wave-uniform control code on register-resident arrays
+  ModelView m = a.model;
+  m.numCuts = numCuts; m.pgDepth = s_tab; m.logPg = s_tab + S4B_MAX_DEPTH; m.log1mPg = s_tab + 2 * S4B_MAX_DEPTH; m.logInt = logInt;
+  m.scratch = s_scratch;
+  const int nc = a.nc;
+  if (doDecide) {
+    const size_t o = (size_t)t * nc;
+    const int cntIn = need;
+    WaveTree cur; WaveTables tb;
+    wave_tree_load(cur, a.var + o, a.cut + o, a.left + o, a.right + o, a.parent + o, hwmT, nc, lane);
+    wave_tree_load(tb.prop, cT.pvar, cT.pcut, cT.pleft, cT.pright, cT.pparent, cntIn, nc, lane);
+    const bool in = lane < cntIn;
+    tb.binA.r = in ? (int)cT.binA[lane] : -1; tb.binB.r = in ? (int)cT.binB[lane] : -1; tb.insub.r = in ? (int)cT.insub[lane] : 0; tb.list.r = 0;
+    WaveArrD mu, muOld, binSum, binCnt; WaveArr<int32_t> cnt;
+    mu.load(lane < hwmT ? a.mu[o + lane] : 0.0); muOld.load(0.0); cnt.r = lane < hwmT ? a.cnt[o + lane] : 0;
+    binSum.load(lane < nb ? ((s_red[0][0][lane] + s_red[0][1][lane]) + s_red[0][2][lane]) + s_red[0][3][lane] : 0.0);
+    binCnt.load(lane < nb ? ((s_red[1][0][lane] + s_red[1][1][lane]) + s_red[1][2][lane]) + s_red[1][3][lane] : 0.0);
+    DecideWork<WaveArrD> wk;
+    wk.ll.load(0.0); wk.lc.load(0.0); wk.ls.load(0.0); wk.u1.load(0.5); wk.u2.load(0.5); wk.val.load(0.0);
+    StepRecord rec; int32_t accepted = 0;
+    const int hwmNew = decide(cur, mu, cnt, muOld, hwmT, m, a.scale->sigma, &s_rng, &s_prT, tb, binCnt, binSum, wk, &accepted, &rec);
+    const int cntOut = s_prT.hwm > hwmNew ? s_prT.hwm : hwmNew;
+    wave_tree_store(cur, a.var + o, a.cut + o, a.left + o, a.right + o, a.parent + o, cntOut, lane);
+    if (lane < cntOut) { a.mu[o + lane] = mu.mine(); a.cnt[o + lane] = cnt.r; cT.muOld[lane] = muOld.mine(); cT.insub[lane] = (uint8_t)tb.insub.r; }
+    if (lane == 0) {
+      a.hwm[t] = hwmNew; *cT.accepted = accepted;
       if (a.traceOn) push_trace(a, rec);
-      s_hwm[0] = lT.prop->hwm > lT.hwm ? lT.prop->hwm : lT.hwm;
-    }
-    if (next >= 0) {
-      lN.hwm = gN.hwm;
-      ctx_propose(lN, m, rng, a.errFlag);
-      *gN.prop = *lN.prop;
-      s_hwm[1] = lN.prop->hwm;
     }
   }
-  __syncthreads();
-  // ---- stage out
-  for (int i = threadIdx.x; i < (int)(sizeof(MTState) / 4); i += BLOCK) ((uint32_t*)a.rng)[i] = ((const uint32_t*)rng)[i];
-  if (doDecide) copy_tree_out(lT, gT, s_hwm[0], true, false);
-  if (next >= 0) copy_tree_out(lN, gN, s_hwm[1], false, true);
+  S4B_TICK(c2);
+  if (next >= 0) {
+    const size_t o = (size_t)next * nc;
+    WaveTree cur; WaveTables tb;
+    wave_tree_load(cur, a.var + o, a.cut + o, a.left + o, a.right + o, a.parent + o, hwmN, nc, lane);
+    tv_fill_info(cur, m, 0);
+    tb.prop = cur;
+    tb.binA.r = -1; tb.binB.r = -1; tb.insub.r = 0; tb.list.r = 0;
+    if (propose(cur, hwmN, m, &s_rng, &s_prN, tb) != 0 && lane == 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
+    const int cntOut = s_prN.hwm;
+    wave_tree_store(tb.prop, cN.pvar, cN.pcut, cN.pleft, cN.pright, cN.pparent, cntOut, lane);
+    if (lane < cntOut) { cN.binA[lane] = (int16_t)tb.binA.r; cN.binB[lane] = (int16_t)tb.binB.r; cN.insub[lane] = (uint8_t)tb.insub.r; }
+    if (lane == 0) *cN.prop = s_prN;
+  }
+  S4B_TICK(c3);
+  // ---- RNG state back to global
+  for (int i = lane; i < (int)(sizeof(MTState) / 4); i += 64) ((uint32_t*)a.rng)[i] = ((const uint32_t*)&s_rng)[i];
+#ifdef S4B_CONTROL_TIMING
+  if (lane == 0 && doDecide && next >= 0) { long long c4 = wall_clock64(); g_dbg[0] += c1 - c0; g_dbg[1] += c2 - c1; g_dbg[2] += c3 - c2; g_dbg[3] += c4 - c3; g_dbg[4] += 1; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -619,13 +680,18 @@ class DevHip {
       c.pvar = zalloc<int16_t>(nc_); c.pleft = zalloc<int16_t>(nc_); c.pright = zalloc<int16_t>(nc_); c.pparent = zalloc<int16_t>(nc_); c.pcut = zalloc<uint16_t>(nc_);
       c.binA = zalloc<int16_t>(nc_); c.binB = zalloc<int16_t>(nc_); c.list = zalloc<int16_t>(nc_); c.insub = zalloc<uint8_t>(nc_);
       c.muOld = zalloc<double>(nc_); c.prop = zalloc<Proposal>(1); c.accepted = zalloc<int32_t>(1);
+      c.cna = zalloc<int16_t>(nc_); c.cdep = zalloc<int16_t>(nc_); c.pna = zalloc<int16_t>(nc_); c.pdep = zalloc<int16_t>(nc_); c.work = zalloc<double>((size_t)12 * nc_);
     }
     a.partCnt = zalloc<double>((size_t)a.binCap * a.grid); a.partSum = zalloc<double>((size_t)a.binCap * a.grid);
     a.binCnt = zalloc<double>((size_t)a.binCap); a.binSum = zalloc<double>((size_t)a.binCap);
     a.rng = zalloc<MTState>(1); a.scale = zalloc<ScaleState>(1);
     int32_t* nc = alloc<int32_t>((size_t)P_); upload(nc, d.numCuts, (size_t)P_); a.numCuts = nc;
     a.trace = zalloc<StepRecord>((size_t)std::max(1, d.traceCap)); a.traceCount = zalloc<int32_t>(1); a.errFlag = zalloc<int32_t>(1);
-    a.model = d.model; a.model.numCuts = nc; a.traceOn = 0;
+    a.model = d.model; a.model.numCuts = nc; a.traceOn = 0; a.model.scratch = nullptr;
+    { double* tb = alloc<double>(3 * S4B_MAX_DEPTH); upload(tb, d.model.pgDepth, (size_t)S4B_MAX_DEPTH); upload(tb + S4B_MAX_DEPTH, d.model.logPg, (size_t)S4B_MAX_DEPTH);
+      upload(tb + 2 * S4B_MAX_DEPTH, d.model.log1mPg, (size_t)S4B_MAX_DEPTH);
+      a.model.pgDepth = tb; a.model.logPg = tb + S4B_MAX_DEPTH; a.model.log1mPg = tb + 2 * S4B_MAX_DEPTH;
+      double* li = alloc<double>((size_t)d.model.logIntLen); upload(li, d.model.logInt, (size_t)d.model.logIntLen); a.model.logInt = li; }
     // ---- Stan-side arrays
     StanArrays& s = s_;
     s = StanArrays{};
@@ -652,11 +718,9 @@ class DevHip {
     if (nTest_) testOut_ = zalloc<double>((size_t)nTest_);
     // ---- launch configuration
     gridN_ = a.grid;   // one launch geometry for every O(N) kernel: the partial buffers are sized by it
-    ldsStats_ = stats_lds_bytes(nc_); ldsApply_ = apply_lds_bytes(nc_); ldsControl_ = control_lds_bytes(nc_, P_);
-    useLds_ = ldsControl_ <= 150 * 1024 ? 1 : 0;
+    ldsStats_ = stats_lds_bytes(nc_); ldsApply_ = apply_lds_bytes(nc_); ldsControl_ = control_lds_bytes(P_, d.model.logIntLen);
     if (ldsStats_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsStats_));
     if (ldsApply_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsApply_));
-    if (useLds_ && ldsControl_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_control), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsControl_));
     if (ldsStats_ > 160 * 1024 || ldsApply_ > 160 * 1024) throw std::runtime_error("node_capacity too large for the 160 KiB LDS of a CU");
     // ---- initial scale from the raw response (offset 0), R = yRescaled
     hipLaunchKernelGGL(k_param_mean, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, 0, 0, 0, 1, a_.offNew); ++launches_;
@@ -720,10 +784,10 @@ class DevHip {
   void assign_leaves_and_residual() { hipLaunchKernelGGL(k_assign_leaves, dim3(gridN_), dim3(BLOCK), 0, stream_, a_); ++launches_; }
   void sweep(int thin) {
     for (int k = 0; k < thin; ++k) {
-      hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), useLds_ ? ldsControl_ : 0, stream_, a_, -1, 0, useLds_); ++launches_;
+      hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsControl_, stream_, a_, -1, 0); ++launches_;
       for (int t = 0; t < T_; ++t) {
         hipLaunchKernelGGL(k_stats, dim3(a_.grid), dim3(BLOCK), ldsStats_, stream_, a_, t); ++launches_;
-        hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), useLds_ ? ldsControl_ : 0, stream_, a_, t, t + 1 < T_ ? t + 1 : -1, useLds_); ++launches_;
+        hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsControl_, stream_, a_, t, t + 1 < T_ ? t + 1 : -1); ++launches_;
         hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, t); ++launches_;
       }
     }
@@ -734,17 +798,17 @@ class DevHip {
     std::vector<hipEvent_t> ev((size_t)perSweep * 2);
     for (auto& e : ev) HIP_OK(hipEventCreate(&e));
     double sum[3] = {0, 0, 0}, cnt[3] = {0, 0, 0};
-    const size_t ldsC = useLds_ ? ldsControl_ : 0;
+    const size_t ldsC = ldsControl_;
     for (int sIdx = 0; sIdx < nSweeps; ++sIdx) {
       size_t e = 0;
       for (int k = 0; k < thin; ++k) {
-        hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsC, stream_, a_, -1, 0, useLds_); ++launches_;
+        hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsC, stream_, a_, -1, 0); ++launches_;
         for (int t = 0; t < T_; ++t) {
           HIP_OK(hipEventRecord(ev[e++], stream_));
           hipLaunchKernelGGL(k_stats, dim3(a_.grid), dim3(BLOCK), ldsStats_, stream_, a_, t);
           HIP_OK(hipEventRecord(ev[e++], stream_));
           HIP_OK(hipEventRecord(ev[e++], stream_));
-          hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsC, stream_, a_, t, t + 1 < T_ ? t + 1 : -1, useLds_);
+          hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsC, stream_, a_, t, t + 1 < T_ ? t + 1 : -1);
           HIP_OK(hipEventRecord(ev[e++], stream_));
           HIP_OK(hipEventRecord(ev[e++], stream_));
           hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, t);
@@ -764,6 +828,9 @@ class DevHip {
     sync();
     float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_));
     out[6] = ms * 1000.0 / nSweeps;
+#ifdef S4B_CONTROL_TIMING
+    { long long h[8]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h))); fprintf(stderr, "DBG control per-call us: stage %.2f decide %.2f propose %.2f out %.2f n=%lld\n", h[0]/100.0/h[4], h[1]/100.0/h[4], h[2]/100.0/h[4], h[3]/100.0/h[4], h[4]); }
+#endif
   }
   void test_fits(double* out) {
     int g = (int)std::min<int64_t>(GRID_MAX, std::max<int64_t>(1, (nTest_ + BLOCK - 1) / BLOCK));
@@ -846,7 +913,7 @@ class DevHip {
   }
 
   int device_ = 0; hipStream_t stream_ = nullptr; hipEvent_t evStart_ = nullptr, evStop_ = nullptr;
-  int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1, useLds_ = 1;
+  int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1;
   size_t ldsStats_ = 0, ldsApply_ = 0, ldsControl_ = 0;
   BartArrays a_; StanArrays s_;
   std::vector<void*> allocs_;

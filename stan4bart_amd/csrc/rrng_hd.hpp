@@ -17,6 +17,20 @@
 #define S4B_HD
 #endif
 
+// S4B_UNI(x): on the device the control code runs wave-uniformly (every lane computes the same scalar
+// program); values that come out of memory are re-broadcast from lane 0 so that the compiler can prove it
+// and emit scalar branches / SGPR loop counters instead of exec-mask divergence handling.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ int s4b_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned s4b_uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ double s4b_uni(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+#define S4B_UNI(x) s4b_uni(x)
+#else
+#define S4B_UNI(x) (x)
+#endif
+
 namespace s4b {
 
 struct MTState {
@@ -37,8 +51,10 @@ S4B_HD inline void mt_regenerate(MTState* s) {
 }
 
 S4B_HD inline uint32_t mt_next(MTState* s) {
-  if (s->mti >= 624) mt_regenerate(s);
-  uint32_t y = s->mt[s->mti++];
+  int k = S4B_UNI((int)s->mti);
+  if (k >= 624) { mt_regenerate(s); k = 0; }
+  uint32_t y = S4B_UNI(s->mt[k]);
+  s->mti = k + 1;
   y ^= (y >> 11);
   y ^= (y << 7) & 0x9d2c5680u;
   y ^= (y << 15) & 0xefc60000u;

@@ -105,9 +105,21 @@ class SamplerCore {
     di.model.base = bc->base; di.model.power = bc->power;
     di.model.pBD = bc->birth_or_death_prob; di.model.pSwap = bc->swap_prob; di.model.pChange = bc->change_prob; di.model.pBirth = bc->birth_prob;
     { double sd_mu = bc->node_scale / (bc->k * std::sqrt((double)T_)); di.model.leafPrec = 1.0 / (sd_mu * sd_mu); }
+    {   // lookup tables of the tree prior, computed with the host libm (device decisions then use the same values)
+      pgDepth_.resize(S4B_MAX_DEPTH); logPg_.resize(S4B_MAX_DEPTH); log1mPg_.resize(S4B_MAX_DEPTH);
+      for (int d = 0; d < S4B_MAX_DEPTH; ++d) {
+        pgDepth_[(size_t)d] = bc->base / std::pow(1.0 + (double)d, bc->power);
+        logPg_[(size_t)d] = std::log(pgDepth_[(size_t)d]); log1mPg_[(size_t)d] = std::log(1.0 - pgDepth_[(size_t)d]);
+      }
+      int maxCuts = 1; for (int j = 0; j < P_; ++j) maxCuts = std::max(maxCuts, numCuts_[(size_t)j]);
+      logInt_.resize((size_t)std::max(P_, maxCuts) + 2);
+      for (size_t k = 0; k < logInt_.size(); ++k) logInt_[k] = std::log((double)k);
+      di.model.pgDepth = pgDepth_.data(); di.model.logPg = logPg_.data(); di.model.log1mPg = log1mPg_.data();
+      di.model.logInt = logInt_.data(); di.model.logIntLen = (int32_t)logInt_.size();
+    }
     di.K = K_; di.q = q_; di.X = sd->X; di.w = sd->w; di.v = sd->v; di.u = sd->u; di.nnz = sd->num_non_zero;
     di.traceCap = 1 << 16;
-    hostModelView_ = di.model; hostModelView_.numCuts = numCuts_.data();
+    hostModelView_ = di.model; hostModelView_.numCuts = numCuts_.data();   // (table pointers are host pointers)
     dev_.init(di);
 
     // ---- Stan sampler: init + init_stepsize run against offset_ = 0 and the raw y (reference
@@ -223,14 +235,14 @@ class SamplerCore {
     for (int t = 0; t < T_; ++t) {
       TreeView tv = h.view(t, nc_);
       std::vector<int32_t> ncount((size_t)nc_, 0);
-      { int nd, k; Walker w(tv, 0);   // post-order: counts of internal nodes
-        while (w.next(nd, k)) { if (k == 0) ncount[(size_t)nd] = h.cnt[(size_t)t * nc_ + nd]; else if (k == 2) ncount[(size_t)nd] = ncount[(size_t)tv.left[nd]] + ncount[(size_t)tv.right[nd]]; } }
-      int nd, k; Walker w(tv, 0);
+      { int nd, k; Walker<TreeView> w(tv, 0);   // post-order: counts of internal nodes
+        while (w.next(nd, k)) { if (k == 0) ncount[(size_t)nd] = h.cnt[(size_t)t * nc_ + nd]; else if (k == 2) ncount[(size_t)nd] = ncount[(size_t)tv.left.get(nd)] + ncount[(size_t)tv.right.get(nd)]; } }
+      int nd, k; Walker<TreeView> w(tv, 0);
       while (w.next(nd, k)) {
         if (k == 2) continue;
         if (cnt < cap && tree) {
           tree[cnt] = t; n_obs[cnt] = ncount[(size_t)nd];
-          if (k == 1) { var[cnt] = tv.var[nd]; split[cnt] = tv.cut[nd]; value[cnt] = cuts_[(size_t)tv.var[nd]][(size_t)tv.cut[nd]]; }
+          if (k == 1) { var[cnt] = tv.var.get(nd); split[cnt] = tv.cut.get(nd); value[cnt] = cuts_[(size_t)tv.var.get(nd)][(size_t)tv.cut.get(nd)]; }
           else { var[cnt] = -1; split[cnt] = -1; value[cnt] = h.mu[(size_t)t * nc_ + nd]; }
         }
         ++cnt;
@@ -245,7 +257,8 @@ class SamplerCore {
     HostTrees h; download_trees(h);
     TreeView tv = h.view(t, nc_);
     std::vector<int16_t> list((size_t)nc_); std::vector<int32_t> rank((size_t)nc_, -1);
-    int nl = tv_list_leaves(tv, 0, list.data());
+    PtrArr<int16_t> la(list.data());
+    int nl = tv_list_leaves(tv, 0, la);
     for (int i = 0; i < nl; ++i) rank[(size_t)list[(size_t)i]] = i;
     std::vector<uint16_t> leaf(n_);
     dev_.download_leaf_plane(t, leaf.data());
@@ -257,10 +270,9 @@ class SamplerCore {
 
  private:
   struct HostTrees {
-    std::vector<int16_t> var, left, right, parent; std::vector<uint16_t> cut; std::vector<double> mu; std::vector<int32_t> cnt, hwm;
-    TreeView view(int t, int nc) { TreeView v; size_t o = (size_t)t * nc; v.var = var.data() + o; v.cut = cut.data() + o; v.left = left.data() + o;
-                                   v.right = right.data() + o; v.parent = parent.data() + o; v.nc = nc; return v; }
-    void alloc(int T, int nc) { size_t m = (size_t)T * nc; var.assign(m, NODE_FREE); left.assign(m, -1); right.assign(m, -1); parent.assign(m, -1);
+    std::vector<int16_t> var, left, right, parent, na, dep; std::vector<uint16_t> cut; std::vector<double> mu; std::vector<int32_t> cnt, hwm;
+    TreeView view(int t, int nc) { size_t o = (size_t)t * nc; return make_tree_view(var.data() + o, cut.data() + o, left.data() + o, right.data() + o, parent.data() + o, nc, na.data(), dep.data()); }
+    void alloc(int T, int nc) { size_t m = (size_t)T * nc; na.assign((size_t)nc, 0); dep.assign((size_t)nc, 0); var.assign(m, NODE_FREE); left.assign(m, -1); right.assign(m, -1); parent.assign(m, -1);
                                 cut.assign(m, 0); mu.assign(m, 0.0); cnt.assign(m, 0); hwm.assign((size_t)T, 1); }
   };
   void download_trees(HostTrees& h) { h.alloc(T_, nc_); dev_.download_trees(h.var.data(), h.cut.data(), h.left.data(), h.right.data(), h.parent.data(), h.mu.data(), h.cnt.data(), h.hwm.data()); }
@@ -299,6 +311,7 @@ class SamplerCore {
 
   // dbarts sampleTreesFromPrior (reference src/init.cpp:261): structure by recursive growth, leaf values from the prior
   void grow(TreeView& tv, int& hwm, int node) {
+    tv_fill_info_node(tv, hostModelView_, node);
     double pg = tv_growth(tv, hostModelView_, node);
     if (pg <= 0.0) return;
     if (!(r_unif(&rng_) < pg)) return;
@@ -306,11 +319,11 @@ class SamplerCore {
     int lo, hi; tv_interval(tv, hostModelView_, node, v, lo, hi);
     int s = r_unif_int(&rng_, lo, hi + 1);
     int L = tv_alloc(tv, hwm); if (L < 0) throw std::runtime_error("node capacity exceeded while sampling trees from the prior");
-    tv.var[L] = NODE_LEAF;
+    tv.var.set(L, NODE_LEAF);
     int R = tv_alloc(tv, hwm); if (R < 0) throw std::runtime_error("node capacity exceeded while sampling trees from the prior");
-    tv.var[node] = (int16_t)v; tv.cut[node] = (uint16_t)s; tv.left[node] = (int16_t)L; tv.right[node] = (int16_t)R;
-    tv.var[L] = NODE_LEAF; tv.parent[L] = (int16_t)node; tv.left[L] = tv.right[L] = -1;
-    tv.var[R] = NODE_LEAF; tv.parent[R] = (int16_t)node; tv.left[R] = tv.right[R] = -1;
+    tv.var.set(node, (int16_t)v); tv.cut.set(node, (uint16_t)s); tv.left.set(node, (int16_t)L); tv.right.set(node, (int16_t)R);
+    tv.var.set(L, NODE_LEAF); tv.parent.set(L, (int16_t)node); tv.left.set(L, -1); tv.right.set(L, -1);
+    tv.var.set(R, NODE_LEAF); tv.parent.set(R, (int16_t)node); tv.left.set(R, -1); tv.right.set(R, -1);
     grow(tv, hwm, L); grow(tv, hwm, R);
   }
   void sample_trees_from_prior() {
@@ -318,10 +331,11 @@ class SamplerCore {
     std::vector<int16_t> list((size_t)nc_);
     for (int t = 0; t < T_; ++t) {
       TreeView tv = h.view(t, nc_);
-      tv.var[0] = NODE_LEAF; tv.parent[0] = -1;
+      tv.var.set(0, NODE_LEAF); tv.parent.set(0, -1);
       int hwm = 1;
       grow(tv, hwm, 0);
-      int nl = tv_list_leaves(tv, 0, list.data());
+      PtrArr<int16_t> la(list.data());
+      int nl = tv_list_leaves(tv, 0, la);
       for (int i = 0; i < nl; ++i) h.mu[(size_t)t * nc_ + list[(size_t)i]] = r_norm(&rng_) / std::sqrt(hostModelView_.leafPrec);
       h.hwm[(size_t)t] = hwm;
     }
@@ -333,7 +347,7 @@ class SamplerCore {
   void var_counts(int32_t* out) {
     HostTrees h; download_trees(h);
     for (int j = 0; j < P_; ++j) out[j] = 0;
-    for (int t = 0; t < T_; ++t) { TreeView tv = h.view(t, nc_); int nd, k; Walker w(tv, 0); while (w.next(nd, k)) if (k == 1) ++out[tv.var[nd]]; }
+    for (int t = 0; t < T_; ++t) { TreeView tv = h.view(t, nc_); int nd, k; Walker<TreeView> w(tv, 0); while (w.next(nd, k)) if (k == 1) ++out[tv.var.get(nd)]; }
   }
 
   // G = [X Z]'[X Z]: constant over the whole run (hmc_mode 0)
@@ -378,6 +392,7 @@ class SamplerCore {
   s4b_callback_fn callback_ = nullptr; void* callbackUser_ = nullptr;
   MTState rng_;
   std::vector<int32_t> numCuts_; std::vector<std::vector<double>> cuts_;
+  std::vector<double> pgDepth_, logPg_, log1mPg_, logInt_;
   ModelView hostModelView_;
   std::unique_ptr<HostModel> model_; std::unique_ptr<Nuts> nuts_;
   std::vector<double> row_, cX_, cZ_, gram_; double s0_ = 0, sigma_ = 1;

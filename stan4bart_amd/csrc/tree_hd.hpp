@@ -3,13 +3,17 @@
 // Replaces the pointer-tree bookkeeping inside dbarts that the reference reaches through
 // bartFunctions.runSamplerWithResults (reference src/init.cpp:824).
 // MI355X-first split of one tree update:
-//   propose()  structure-only: picks the move and builds the proposed tree + bin maps   (1 lane)
+//   propose()  structure-only: picks the move and builds the proposed tree + bin maps
 //   stats      O(N) HIP kernel: per-leaf (count, sum) of the partial residual for the current
 //              leaves ("A bins") and for the leaves the proposal would create ("B bins")
-//   decide()   integrated-likelihood ratio from the bins, accept/reject, leaf draws       (1 lane)
+//   decide()   integrated-likelihood ratio from the bins, accept/reject, leaf draws
 //   apply      O(N) HIP kernel: residual update + leaf relabelling
-// propose()/decide() never touch per-observation data, so they run as one lane of a tiny kernel
-// (no host round trip inside the sweep) and compile for the host as well.
+// propose()/decide() never touch per-observation data.  They are written against an abstract array
+// accessor (get/set), so the same source runs
+//   * on the device with every small array spread over the 64 lanes of one wavefront and read
+//     with v_readlane (WaveArr in dev_hip.hip) — wave-uniform scalar code with ~register latency —
+//     or on LDS/global pointers for trees with more than 64 node slots,
+//   * on the host on plain pointers (tree initialisation; CPU tests of the host logic).
 // The move definitions, draw order and probabilities are those written down in
 // DESIGN.md §"BART specification".
 #ifndef S4B_TREE_HD_HPP
@@ -22,15 +26,37 @@ namespace s4b {
 enum : int16_t { NODE_LEAF = -1, NODE_FREE = -2 };
 enum : int32_t { MOVE_BIRTH = 0, MOVE_DEATH = 1, MOVE_SWAP = 2, MOVE_CHANGE = 3 };
 
-struct TreeView {
-  int16_t* var;      // >= 0 split variable | NODE_LEAF | NODE_FREE
-  uint16_t* cut;     // split index: go left iff xbin <= cut
-  int16_t* left;
-  int16_t* right;
-  int16_t* parent;   // -1 for the root (node 0)
-  int32_t nc;        // slot capacity
+// ------------------------------------------------------------------ storage: plain pointers
+template <class T>
+struct PtrArr {
+  T* p;
+  S4B_HD PtrArr() : p(nullptr) {}
+  S4B_HD explicit PtrArr(T* q) : p(q) {}
+  S4B_HD T get(int i) const { return p[i]; }
+  S4B_HD void set(int i, T v) const { p[i] = v; }
 };
 
+// a tree over any array storage AI16/AU16 (int16 / uint16 element arrays)
+template <class AI16, class AU16>
+struct TreeT {
+  AI16 var;      // >= 0 split variable | NODE_LEAF | NODE_FREE
+  AU16 cut;      // split index: go left iff xbin <= cut
+  AI16 left, right, parent;   // parent = -1 for the root (node 0)
+  AI16 na;       // memo: number of predictors still available at the node (valid after tv_fill_info)
+  AI16 dep;      // memo: depth of the node
+  int32_t nc;    // slot capacity
+};
+typedef TreeT<PtrArr<int16_t>, PtrArr<uint16_t>> TreeView;
+
+S4B_HD inline TreeView make_tree_view(int16_t* var, uint16_t* cut, int16_t* left, int16_t* right, int16_t* parent, int nc,
+                                      int16_t* na = nullptr, int16_t* dep = nullptr) {
+  TreeView t; t.var = PtrArr<int16_t>(var); t.cut = PtrArr<uint16_t>(cut); t.left = PtrArr<int16_t>(left);
+  t.right = PtrArr<int16_t>(right); t.parent = PtrArr<int16_t>(parent); t.na = PtrArr<int16_t>(na); t.dep = PtrArr<int16_t>(dep); t.nc = nc;
+  return t;
+}
+
+// constants of the BART model + lookup tables computed once on the host (so that device decisions use the
+// same libm values a CPU implementation would)
 struct ModelView {
   int32_t P;                 // number of BART predictors
   int32_t Pvalid;            // predictors with at least one cut point
@@ -38,7 +64,19 @@ struct ModelView {
   double base, power;        // tree prior
   double pBD, pSwap, pChange, pBirth;   // proposal mix
   double leafPrec;           // leaf prior precision  (k sqrt(T) / node_scale)^2
+  const double* pgDepth;     // [MAX_DEPTH]  base / (1 + d)^power
+  const double* logPg;       // [MAX_DEPTH]  log(pgDepth[d])
+  const double* log1mPg;     // [MAX_DEPTH]  log(1 - pgDepth[d])
+  const double* logInt;      // [logIntLen]  log((double)k), k >= 1
+  int32_t logIntLen;
+  double* scratch;           // optional [S4B_MAX_DEPTH] work array (device: LDS); nullptr -> stack
 };
+enum { S4B_MAX_DEPTH = 128 };
+#if defined(__HIP_DEVICE_COMPILE__)
+enum { S4B_MAX_DEPTH_LOCAL = 1 };     // device code always passes an LDS scratch array
+#else
+enum { S4B_MAX_DEPTH_LOCAL = S4B_MAX_DEPTH };
+#endif
 
 // everything the O(N) kernels and decide() need to know about the pending move of one tree
 struct Proposal {
@@ -55,42 +93,65 @@ struct Proposal {
 
 struct StepRecord { int32_t type, status, var, split, numLeaves; };
 
-// per-tree scratch tables (length nc each); `p*` is the proposed tree
-struct StepTables {
-  TreeView prop;
-  int16_t* binA;      // current leaf -> A bin, -1 otherwise
-  int16_t* binB;      // proposed leaf under `node` -> B bin (offset by nbA), -1 otherwise
-  uint8_t* insub;     // current leaf lies under `node` (needs re-routing through the proposed tree)
-  int16_t* list;      // scratch node list
+// per-tree scratch tables; `prop` is the proposed tree
+template <class TR, class AI16, class AU8>
+struct StepTablesT {
+  TR prop;
+  AI16 binA;      // current leaf -> A bin, -1 otherwise
+  AI16 binB;      // proposed leaf under `node` -> B bin (offset by nbA), -1 otherwise
+  AU8 insub;      // current leaf lies under `node` (needs re-routing through the proposed tree)
+  AI16 list;      // scratch node list
 };
+typedef StepTablesT<TreeView, PtrArr<int16_t>, PtrArr<uint8_t>> StepTables;
 
 // ------------------------------------------------------------------ structure helpers
-S4B_HD inline bool tv_is_leaf(const TreeView& t, int n) { return t.var[n] == NODE_LEAF; }
+template <class TR> S4B_HD inline bool tv_is_leaf(const TR& t, int n) { return t.var.get(n) == NODE_LEAF; }
 
-S4B_HD inline int tv_depth(const TreeView& t, int n) {
+template <class TR> S4B_HD inline int tv_depth(const TR& t, int n) {
   int d = 0;
-  for (int a = t.parent[n]; a >= 0; a = t.parent[a]) ++d;
+  for (int a = t.parent.get(n); a >= 0; a = t.parent.get(a)) ++d;
   return d;
 }
 
 // valid cut interval [lo, hi] of variable v at node n given the rules of its ancestors
-S4B_HD inline void tv_interval(const TreeView& t, const ModelView& m, int n, int v, int& lo, int& hi) {
-  lo = 0; hi = m.numCuts[v] - 1;
+template <class TR> S4B_HD inline void tv_interval(const TR& t, const ModelView& m, int n, int v, int& lo, int& hi) {
+  lo = 0; hi = S4B_UNI(m.numCuts[v]) - 1;
   int child = n;
-  for (int a = t.parent[n]; a >= 0; child = a, a = t.parent[a]) {
-    if (t.var[a] != v) continue;
-    int s = (int)t.cut[a];
-    if (child == t.left[a]) { if (s - 1 < hi) hi = s - 1; }
+  for (int a = t.parent.get(n); a >= 0; child = a, a = t.parent.get(a)) {
+    if (t.var.get(a) != v) continue;
+    int s = (int)t.cut.get(a);
+    if (child == t.left.get(a)) { if (s - 1 < hi) hi = s - 1; }
     else { if (s + 1 > lo) lo = s + 1; }
   }
 }
 
-S4B_HD inline int tv_num_avail(const TreeView& t, const ModelView& m, int n) {
+// stackless walk of the subtree rooted at `root`:
+//   kind 0 = leaf, 1 = internal node on the way down (pre-order), 2 = internal node on the way up (post-order)
+template <class TR>
+struct Walker {
+  const TR* t; int stop, cur, prev;
+  S4B_HD Walker(const TR& tv, int r) : t(&tv), stop(tv.parent.get(r)), cur(r), prev(tv.parent.get(r)) {}
+  S4B_HD bool next(int& node, int& kind) {
+    while (cur != stop) {
+      int c = cur;
+      int par = t->parent.get(c);
+      if (t->var.get(c) == NODE_LEAF) { node = c; kind = 0; prev = c; cur = par; return true; }
+      if (prev == par) { node = c; kind = 1; prev = c; cur = t->left.get(c); return true; }
+      if (prev == t->left.get(c)) { prev = c; cur = t->right.get(c); continue; }
+      node = c; kind = 2; prev = c; cur = par; return true;
+    }
+    return false;
+  }
+};
+
+// number of predictors that still have a free cut at node n.  Only predictors used by an ancestor can be
+// exhausted; each is counted once (at its lowest ancestor)
+template <class TR> S4B_HD inline int tv_num_avail_compute(const TR& t, const ModelView& m, int n) {
   int exhausted = 0;
-  for (int a = t.parent[n]; a >= 0; a = t.parent[a]) {
-    int v = t.var[a];
-    bool seen = false;   // count each variable once: at its lowest ancestor
-    for (int b = t.parent[n]; b != a; b = t.parent[b]) if (t.var[b] == v) { seen = true; break; }
+  for (int a = t.parent.get(n); a >= 0; a = t.parent.get(a)) {
+    int v = t.var.get(a);
+    bool seen = false;
+    for (int b = t.parent.get(n); b != a; b = t.parent.get(b)) if (t.var.get(b) == v) { seen = true; break; }
     if (seen) continue;
     int lo, hi; tv_interval(t, m, n, v, lo, hi);
     if (lo > hi) ++exhausted;
@@ -98,14 +159,41 @@ S4B_HD inline int tv_num_avail(const TreeView& t, const ModelView& m, int n) {
   return m.Pvalid - exhausted;
 }
 
-S4B_HD inline double tv_growth(const TreeView& t, const ModelView& m, int n) {
+// memoised per-node info: fill once per (tree, step); afterwards tv_num_avail / tv_depth_of are O(1)
+template <class TR> S4B_HD inline void tv_fill_info_node(TR& t, const ModelView& m, int n) {
+  t.na.set(n, (int16_t)tv_num_avail_compute(t, m, n)); t.dep.set(n, (int16_t)tv_depth(t, n));
+}
+template <class TR> S4B_HD inline void tv_fill_info(TR& t, const ModelView& m, int root) {
+  int nd, k; Walker<TR> w(t, root);
+  while (w.next(nd, k)) if (k != 2) tv_fill_info_node(t, m, nd);
+}
+template <class TR> S4B_HD inline int tv_num_avail(const TR& t, const ModelView&, int n) { return (int)t.na.get(n); }
+template <class TR> S4B_HD inline int tv_depth_of(const TR& t, int n) { return (int)t.dep.get(n); }
+template <class TR> S4B_HD inline double tv_growth(const TR& t, const ModelView& m, int n) {
   if (tv_num_avail(t, m, n) == 0) return 0.0;
-  return m.base / pow(1.0 + (double)tv_depth(t, n), m.power);
+  return S4B_UNI(m.pgDepth[tv_depth_of(t, n)]);
 }
 
-S4B_HD inline int tv_draw_var(const TreeView& t, const ModelView& m, int n, MTState* rng) {
-  int good = tv_num_avail(t, m, n);
-  int idx = r_unif_int(rng, 0, good);
+// the idx-th (0-based) predictor, in increasing order, that is available at node n
+template <class TR> S4B_HD inline int tv_nth_avail_var(const TR& t, const ModelView& m, int n, int idx) {
+  if (m.Pvalid == m.P) {
+    // fast path: only ancestors' predictors can be unavailable; bump the candidate past every exhausted
+    // predictor <= it, smallest first
+    int v = idx;
+    int last = -1;
+    for (;;) {
+      // smallest exhausted predictor in (last, v]
+      int best = -1;
+      for (int a = t.parent.get(n); a >= 0; a = t.parent.get(a)) {
+        int av = t.var.get(a);
+        if (av <= last || av > v || (best >= 0 && av >= best)) continue;
+        int lo, hi; tv_interval(t, m, n, av, lo, hi);
+        if (lo > hi) best = av;
+      }
+      if (best < 0) return v;
+      last = best; ++v;
+    }
+  }
   for (int v = 0; v < m.P; ++v) {
     if (m.numCuts[v] <= 0) continue;
     int lo, hi; tv_interval(t, m, n, v, lo, hi);
@@ -114,178 +202,189 @@ S4B_HD inline int tv_draw_var(const TreeView& t, const ModelView& m, int n, MTSt
   return -1;
 }
 
-// stackless walk of the subtree rooted at `root`.  Calls back through `kind`:
-//   0 = leaf, 1 = internal node on the way down (pre-order), 2 = internal node on the way up (post-order)
-struct Walker {
-  const TreeView* t; int root, stop, cur, prev;
-  S4B_HD Walker(const TreeView& tv, int r) : t(&tv), root(r), stop(tv.parent[r]), cur(r), prev(tv.parent[r]) {}
-  // returns false when done; otherwise sets node/kind
-  S4B_HD bool next(int& node, int& kind) {
-    while (cur != stop) {
-      int c = cur;
-      if (t->var[c] == NODE_LEAF) { node = c; kind = 0; prev = c; cur = t->parent[c]; return true; }
-      if (prev == t->parent[c]) { node = c; kind = 1; prev = c; cur = t->left[c]; return true; }
-      if (prev == t->left[c]) { prev = c; cur = t->right[c]; continue; }
-      node = c; kind = 2; prev = c; cur = t->parent[c]; return true;
-    }
-    return false;
-  }
-};
+template <class TR> S4B_HD inline int tv_draw_var(const TR& t, const ModelView& m, int n, MTState* rng) {
+  int good = tv_num_avail(t, m, n);
+  int idx = r_unif_int(rng, 0, good);
+  return tv_nth_avail_var(t, m, n, idx);
+}
 
-S4B_HD inline int tv_list_leaves(const TreeView& t, int root, int16_t* out) {
-  int cnt = 0, nd, k; Walker w(t, root);
-  while (w.next(nd, k)) if (k == 0) out[cnt++] = (int16_t)nd;
+template <class TR, class AI16> S4B_HD inline int tv_list_leaves(const TR& t, int root, AI16& out) {
+  int cnt = 0, nd, k; Walker<TR> w(t, root);
+  while (w.next(nd, k)) if (k == 0) out.set(cnt++, (int16_t)nd);
   return cnt;
 }
-S4B_HD inline int tv_list_not_bottom(const TreeView& t, int16_t* out) {   // post-order
-  int cnt = 0, nd, k; Walker w(t, 0);
-  while (w.next(nd, k)) if (k == 2) out[cnt++] = (int16_t)nd;
+template <class TR, class AI16> S4B_HD inline int tv_list_not_bottom(const TR& t, AI16& out) {   // post-order
+  int cnt = 0, nd, k; Walker<TR> w(t, 0);
+  while (w.next(nd, k)) if (k == 2) out.set(cnt++, (int16_t)nd);
   return cnt;
 }
-S4B_HD inline bool tv_is_nog(const TreeView& t, int n) {
-  return t.var[n] >= 0 && t.var[t.left[n]] == NODE_LEAF && t.var[t.right[n]] == NODE_LEAF;
+template <class TR> S4B_HD inline bool tv_is_nog(const TR& t, int n) {
+  return t.var.get(n) >= 0 && t.var.get(t.left.get(n)) == NODE_LEAF && t.var.get(t.right.get(n)) == NODE_LEAF;
 }
-S4B_HD inline int tv_list_nog(const TreeView& t, int16_t* out) {   // order of first visit
-  int cnt = 0, nd, k; Walker w(t, 0);
-  while (w.next(nd, k)) if (k == 1 && tv_is_nog(t, nd)) out[cnt++] = (int16_t)nd;
+template <class TR, class AI16> S4B_HD inline int tv_list_nog(const TR& t, AI16& out) {   // order of first visit
+  int cnt = 0, nd, k; Walker<TR> w(t, 0);
+  while (w.next(nd, k)) if (k == 1 && tv_is_nog(t, nd)) out.set(cnt++, (int16_t)nd);
   return cnt;
 }
-S4B_HD inline int tv_list_swappable(const TreeView& t, int16_t* out) {   // post-order
-  int cnt = 0, nd, k; Walker w(t, 0);
-  while (w.next(nd, k)) if (k == 2 && !tv_is_nog(t, nd)) out[cnt++] = (int16_t)nd;
+template <class TR> S4B_HD inline int tv_count_nog(const TR& t) {
+  int cnt = 0, nd, k; Walker<TR> w(t, 0);
+  while (w.next(nd, k)) if (k == 1 && tv_is_nog(t, nd)) ++cnt;
   return cnt;
 }
-S4B_HD inline int tv_list_growable(const TreeView& t, const ModelView& m, int16_t* out) {   // DFS order
-  int cnt = 0, nd, k; Walker w(t, 0);
-  while (w.next(nd, k)) if (k == 0 && tv_growth(t, m, nd) > 0.0) out[cnt++] = (int16_t)nd;
+template <class TR, class AI16> S4B_HD inline int tv_list_swappable(const TR& t, AI16& out) {   // post-order
+  int cnt = 0, nd, k; Walker<TR> w(t, 0);
+  while (w.next(nd, k)) if (k == 2 && !tv_is_nog(t, nd)) out.set(cnt++, (int16_t)nd);
+  return cnt;
+}
+template <class TR, class AI16> S4B_HD inline int tv_list_growable(const TR& t, const ModelView& m, AI16& out) {   // DFS order
+  int cnt = 0, nd, k; Walker<TR> w(t, 0);
+  while (w.next(nd, k)) if (k == 0 && tv_num_avail(t, m, nd) > 0) out.set(cnt++, (int16_t)nd);
+  return cnt;
+}
+template <class TR> S4B_HD inline int tv_count_growable(const TR& t, const ModelView& m) {
+  int cnt = 0, nd, k; Walker<TR> w(t, 0);
+  while (w.next(nd, k)) if (k == 0 && tv_num_avail(t, m, nd) > 0) ++cnt;
   return cnt;
 }
 
-S4B_HD inline double tv_prob_birth_step(const TreeView& t, const ModelView& m) {
+// P(birth step | tree) given the number of leaves that can still grow
+template <class TR> S4B_HD inline double tv_prob_birth_step(const TR& t, const ModelView& m, int numGrowable) {
   if (tv_is_leaf(t, 0)) return 1.0;
-  int nd, k; Walker w(t, 0);
-  while (w.next(nd, k)) if (k == 0 && tv_growth(t, m, nd) > 0.0) return m.pBirth;
-  return 0.0;
+  return numGrowable > 0 ? m.pBirth : 0.0;
 }
 
-// log tree prior, accumulated in pre-order (node, left subtree, right subtree)
-S4B_HD inline double tv_log_prior(const TreeView& t, const ModelView& m) {
-  // r(n) = own(n) + r(left) + r(right) evaluated with an explicit post-order accumulation so the
-  // floating-point association equals the recursive definition: own + (left) + (right)
-  // done iteratively: value stack bounded by depth; we keep partial sums in `acc` indexed by depth.
-  const int MAXD = 64;
-  double acc[MAXD];
-  int depth = 0, nd, k; Walker w(t, 0);
+// log tree prior: own(n) + subtree(left) + subtree(right), associated exactly like the recursion
+template <class TR> S4B_HD inline double tv_log_prior(const TR& t, const ModelView& m) {
+  double accLocal[S4B_MAX_DEPTH_LOCAL];
+  double* acc = m.scratch ? m.scratch : accLocal;
+  int depth = 0, nd, k; Walker<TR> w(t, 0);
   double result = 0.0;
   while (w.next(nd, k)) {
     if (k == 0) {
-      double v = log(1.0 - tv_growth(t, m, nd));
+      double v = tv_num_avail(t, m, nd) == 0 ? 0.0 /* log(1 - 0) */ : S4B_UNI(m.log1mPg[depth]);
       if (depth == 0) result = v; else acc[depth - 1] += v;
     } else if (k == 1) {
-      double r = log(tv_growth(t, m, nd));
-      r += -log((double)tv_num_avail(t, m, nd));
-      int lo, hi; tv_interval(t, m, nd, t.var[nd], lo, hi);
-      r += -log((double)(hi - lo + 1));
-      if (depth < MAXD) acc[depth] = r;
+      int na = tv_num_avail(t, m, nd);
+      double r = na == 0 ? -INFINITY : S4B_UNI(m.logPg[depth]);
+      r += -S4B_UNI(m.logInt[na]);
+      int lo, hi; tv_interval(t, m, nd, t.var.get(nd), lo, hi);
+      int width = hi - lo + 1;
+      r += (width >= 1 && width < m.logIntLen) ? -S4B_UNI(m.logInt[width]) : -log((double)width);
+      acc[depth] = r;
       ++depth;
     } else {
       --depth;
-      double v = acc[depth];
+      double v = S4B_UNI(acc[depth]);
       if (depth == 0) result = v; else acc[depth - 1] += v;
     }
   }
   return result;
 }
 
-S4B_HD inline void tv_copy(const TreeView& src, const TreeView& dst, int count) {
+template <class TA, class TB> S4B_HD inline void tv_copy(const TA& src, TB& dst, int count) {
   for (int i = 0; i < count; ++i) {
-    dst.var[i] = src.var[i]; dst.cut[i] = src.cut[i]; dst.left[i] = src.left[i]; dst.right[i] = src.right[i]; dst.parent[i] = src.parent[i];
+    dst.var.set(i, src.var.get(i)); dst.cut.set(i, src.cut.get(i)); dst.left.set(i, src.left.get(i));
+    dst.right.set(i, src.right.get(i)); dst.parent.set(i, src.parent.get(i)); dst.na.set(i, src.na.get(i)); dst.dep.set(i, src.dep.get(i));
   }
 }
 
-S4B_HD inline int tv_alloc(const TreeView& t, int& hwm) {
-  for (int i = 0; i < hwm; ++i) if (t.var[i] == NODE_FREE) return i;
+template <class TR> S4B_HD inline int tv_alloc(const TR& t, int& hwm) {
+  for (int i = 0; i < hwm; ++i) if (t.var.get(i) == NODE_FREE) return i;
   if (hwm >= t.nc) return -1;
   return hwm++;
 }
 
-S4B_HD inline void tv_min_max_split(const TreeView& t, int root, int v, int& mn, int& mx) {
-  int nd, k; Walker w(t, root);
-  while (w.next(nd, k)) if (k == 1 && t.var[nd] == v) { int s = (int)t.cut[nd]; if (s < mn) mn = s; if (s > mx) mx = s; }
+template <class TR> S4B_HD inline void tv_min_max_split(const TR& t, int root, int v, int& mn, int& mx) {
+  int nd, k; Walker<TR> w(t, root);
+  while (w.next(nd, k)) if (k == 1 && t.var.get(nd) == v) { int s = (int)t.cut.get(nd); if (s < mn) mn = s; if (s > mx) mx = s; }
 }
 
-S4B_HD inline bool tv_rules_valid(const TreeView& t, const ModelView& m, int root) {
-  int nd, k; Walker w(t, root);
+template <class TR> S4B_HD inline bool tv_rules_valid(const TR& t, const ModelView& m, int root) {
+  int nd, k; Walker<TR> w(t, root);
   while (w.next(nd, k)) if (k == 1) {
-    int lo, hi; tv_interval(t, m, nd, t.var[nd], lo, hi);
-    int s = (int)t.cut[nd];
+    int lo, hi; tv_interval(t, m, nd, t.var.get(nd), lo, hi);
+    int s = (int)t.cut.get(nd);
     if (s < lo || s > hi) return false;
   }
   return true;
 }
 
 // ------------------------------------------------------------------ propose
-// Fills `pr` and the tables for the next update of tree `cur` (hwm = slots in use).
+// Fills `pr` and the tables for the next update of tree `cur` (hwm = slots in use).  Preconditions: the node
+// memo of `cur` is filled (tv_fill_info), the proposed tree is a copy of `cur` (memo included) for node
+// ids < hwm, and binA/binB = -1, insub = 0 there.
 // Returns 0, or -1 when the node capacity is exhausted (the caller raises an error).
-S4B_HD inline int propose(const TreeView& cur, int hwm, const ModelView& m, MTState* rng, Proposal* pr, const StepTables& tb) {
-  const TreeView& pt = tb.prop;
-  tv_copy(cur, pt, hwm);
-  for (int i = 0; i < hwm; ++i) { tb.binA[i] = -1; tb.binB[i] = -1; tb.insub[i] = 0; }
+template <class TR, class TBL>
+S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* rng, Proposal* pr, TBL& tb) {
+  TR& pt = tb.prop;
   int nl = tv_list_leaves(cur, 0, tb.list);
-  for (int i = 0; i < nl; ++i) tb.binA[tb.list[i]] = (int16_t)i;
+  for (int i = 0; i < nl; ++i) tb.binA.set(tb.list.get(i), (int16_t)i);
   pr->nbA = nl; pr->nbB = 0; pr->hwm = hwm; pr->node = 0; pr->var = -1; pr->split = -1; pr->status = -1;
   pr->newLeft = pr->newRight = -1; pr->priorRatio = pr->transRatio = 1.0; pr->XLogPi = pr->YLogPi = 0.0;
 
   double u = r_unif(rng);
   if (u < m.pBD) {
-    double pBirthStep = tv_prob_birth_step(cur, m);
+    const bool single = tv_is_leaf(cur, 0);
+    int g = single ? 1 : tv_list_growable(cur, m, tb.list);
+    double pBirthStep = tv_prob_birth_step(cur, m, g);
     if (r_unif(rng) < pBirthStep) {
       pr->type = MOVE_BIRTH;
       int nd; double pSelect;
-      if (tv_is_leaf(cur, 0)) { nd = 0; pSelect = 1.0; }
+      if (single) { nd = 0; pSelect = 1.0; }
       else {
-        int g = tv_list_growable(cur, m, tb.list);
         if (g == 0) return 0;
-        nd = tb.list[r_unif_int(rng, 0, g)];
+        nd = tb.list.get(r_unif_int(rng, 0, g));
         pSelect = 1.0 / (double)g;
       }
-      double pgParent = tv_growth(cur, m, nd);
+      int depthNd = tv_depth_of(cur, nd);
+      double pgParent = S4B_UNI(m.pgDepth[depthNd]);      // nd is growable: numAvail > 0
       int v = tv_draw_var(cur, m, nd, rng);
       int lo, hi; tv_interval(cur, m, nd, v, lo, hi);
       int s = r_unif_int(rng, lo, hi + 1);
       int h2 = hwm;
       int L = tv_alloc(pt, h2); if (L < 0) return -1;
-      pt.var[L] = NODE_LEAF;
+      pt.var.set(L, NODE_LEAF);
       int R = tv_alloc(pt, h2); if (R < 0) return -1;
-      pt.var[nd] = (int16_t)v; pt.cut[nd] = (uint16_t)s; pt.left[nd] = (int16_t)L; pt.right[nd] = (int16_t)R;
-      pt.var[L] = NODE_LEAF; pt.left[L] = pt.right[L] = -1; pt.parent[L] = (int16_t)nd; pt.cut[L] = 0;
-      pt.var[R] = NODE_LEAF; pt.left[R] = pt.right[R] = -1; pt.parent[R] = (int16_t)nd; pt.cut[R] = 0;
-      for (int i = hwm; i < h2; ++i) { tb.binA[i] = -1; tb.binB[i] = -1; tb.insub[i] = 0; }
-      double pgL = tv_growth(pt, m, L), pgR = tv_growth(pt, m, R);
+      pt.var.set(nd, (int16_t)v); pt.cut.set(nd, (uint16_t)s); pt.left.set(nd, (int16_t)L); pt.right.set(nd, (int16_t)R);
+      pt.var.set(L, NODE_LEAF); pt.left.set(L, -1); pt.right.set(L, -1); pt.parent.set(L, (int16_t)nd); pt.cut.set(L, 0);
+      pt.var.set(R, NODE_LEAF); pt.left.set(R, -1); pt.right.set(R, -1); pt.parent.set(R, (int16_t)nd); pt.cut.set(R, 0);
+      for (int i = hwm; i < h2; ++i) { tb.binA.set(i, -1); tb.binB.set(i, -1); tb.insub.set(i, 0); }
+      double pgChild = S4B_UNI(m.pgDepth[depthNd + 1]);
+      tv_fill_info_node(pt, m, L); tv_fill_info_node(pt, m, R);
+      int naL = tv_num_avail(pt, m, L), naR = tv_num_avail(pt, m, R);
+      double pgL = naL == 0 ? 0.0 : pgChild, pgR = naR == 0 ? 0.0 : pgChild;
       double newPrior = pgParent * (1.0 - pgL) * (1.0 - pgR);
       double oldPrior = 1.0 - pgParent;
-      double pDeath = 1.0 - tv_prob_birth_step(pt, m);
-      int nog = tv_list_nog(pt, tb.list);
+      // growable leaves of the proposed tree: the old ones minus nd plus the children that can grow
+      int gNew = (single ? 0 : g - 1) + (naL > 0 ? 1 : 0) + (naR > 0 ? 1 : 0);
+      double pDeath = 1.0 - (gNew > 0 ? m.pBirth : 0.0);
+      int nog = tv_count_nog(pt);
       double pSelectDeath = 1.0 / (double)nog;
       pr->priorRatio = newPrior / oldPrior;
       pr->transRatio = (pDeath * pSelectDeath) / (pBirthStep * pSelect);
       pr->node = nd; pr->var = v; pr->split = s; pr->newLeft = L; pr->newRight = R; pr->hwm = h2;
-      tb.insub[nd] = 1; tb.binB[L] = (int16_t)nl; tb.binB[R] = (int16_t)(nl + 1); pr->nbB = 2;
+      tb.insub.set(nd, 1); tb.binB.set(L, (int16_t)nl); tb.binB.set(R, (int16_t)(nl + 1)); pr->nbB = 2;
       pr->status = 1;
     } else {
       pr->type = MOVE_DEATH;
-      int g = tv_list_nog(cur, tb.list);
-      if (g == 0) return 0;
-      int nd = tb.list[r_unif_int(rng, 0, g)];
-      double pSelect = 1.0 / (double)g;
-      int L = cur.left[nd], R = cur.right[nd];
-      double pgParent = tv_growth(cur, m, nd), pgL = tv_growth(cur, m, L), pgR = tv_growth(cur, m, R);
+      int gn = tv_list_nog(cur, tb.list);
+      if (gn == 0) return 0;
+      int nd = tb.list.get(r_unif_int(rng, 0, gn));
+      double pSelect = 1.0 / (double)gn;
+      int L = cur.left.get(nd), R = cur.right.get(nd);
+      int depthNd = tv_depth_of(cur, nd);
+      int naP = tv_num_avail(cur, m, nd), naL = tv_num_avail(cur, m, L), naR = tv_num_avail(cur, m, R);
+      double pgParent = naP == 0 ? 0.0 : S4B_UNI(m.pgDepth[depthNd]);
+      double pgC = S4B_UNI(m.pgDepth[depthNd + 1]);
+      double pgL = naL == 0 ? 0.0 : pgC, pgR = naR == 0 ? 0.0 : pgC;
       double oldPrior = pgParent * (1.0 - pgL) * (1.0 - pgR);
-      pt.var[nd] = NODE_LEAF; pt.left[nd] = pt.right[nd] = -1; pt.cut[nd] = 0;
-      pt.var[L] = NODE_FREE; pt.var[R] = NODE_FREE;
-      double newPrior = 1.0 - tv_growth(pt, m, nd);
-      double pBirthNew = tv_prob_birth_step(pt, m);
-      int numGood = tv_is_leaf(pt, 0) ? 1 : tv_list_growable(pt, m, tb.list);
+      pt.var.set(nd, NODE_LEAF); pt.left.set(nd, -1); pt.right.set(nd, -1); pt.cut.set(nd, 0);
+      pt.var.set(L, NODE_FREE); pt.var.set(R, NODE_FREE);
+      double newPrior = 1.0 - pgParent;
+      const bool singleNew = tv_is_leaf(pt, 0);
+      // growable leaves after the collapse: remove the two children, add the parent
+      int numGood = singleNew ? 1 : g - (naL > 0 ? 1 : 0) - (naR > 0 ? 1 : 0) + (naP > 0 ? 1 : 0);
+      double pBirthNew = singleNew ? 1.0 : (numGood > 0 ? m.pBirth : 0.0);
       double pSelectBirth = 1.0 / (double)numGood;
       double pDeath = 1.0 - pBirthStep;
       pr->priorRatio = newPrior / oldPrior;
@@ -296,49 +395,52 @@ S4B_HD inline int propose(const TreeView& cur, int hwm, const ModelView& m, MTSt
     pr->type = MOVE_SWAP;
     int g = tv_list_swappable(cur, tb.list);
     if (g == 0) return 0;
-    int nd = tb.list[r_unif_int(rng, 0, g)];
-    int L = cur.left[nd], R = cur.right[nd];
-    bool both = cur.var[L] >= 0 && cur.var[R] >= 0 && cur.var[L] == cur.var[R] && cur.cut[L] == cur.cut[R];
+    int nd = tb.list.get(r_unif_int(rng, 0, g));
+    int L = cur.left.get(nd), R = cur.right.get(nd);
+    int vL = cur.var.get(L), vR = cur.var.get(R);
+    bool both = vL >= 0 && vR >= 0 && vL == vR && cur.cut.get(L) == cur.cut.get(R);
     int child = -1;
     if (!both) {
-      if (cur.var[L] < 0) child = R;
-      else if (cur.var[R] < 0) child = L;
+      if (vL < 0) child = R;
+      else if (vR < 0) child = L;
       else child = (r_unif(rng) < 0.5) ? L : R;
     }
-    int16_t pv = cur.var[nd]; uint16_t ps = cur.cut[nd];
-    int16_t cv = both ? cur.var[L] : cur.var[child]; uint16_t cs = both ? cur.cut[L] : cur.cut[child];
+    int16_t pv = cur.var.get(nd); uint16_t ps = cur.cut.get(nd);
+    int16_t cv = both ? (int16_t)vL : cur.var.get(child); uint16_t cs = both ? cur.cut.get(L) : cur.cut.get(child);
     pr->node = nd;
-    pt.var[nd] = cv; pt.cut[nd] = cs;
-    if (both) { pt.var[L] = pv; pt.cut[L] = ps; pt.var[R] = pv; pt.cut[R] = ps; }
-    else { pt.var[child] = pv; pt.cut[child] = ps; }
+    pt.var.set(nd, cv); pt.cut.set(nd, cs);
+    if (both) { pt.var.set(L, pv); pt.cut.set(L, ps); pt.var.set(R, pv); pt.cut.set(R, ps); }
+    else { pt.var.set(child, pv); pt.cut.set(child, ps); }
     if (!tv_rules_valid(pt, m, nd)) return 0;
+    tv_fill_info(pt, m, nd);
     pr->XLogPi = tv_log_prior(cur, m);
     pr->YLogPi = tv_log_prior(pt, m);
     int nb = tv_list_leaves(pt, nd, tb.list);
-    for (int i = 0; i < nb; ++i) { tb.binB[tb.list[i]] = (int16_t)(nl + i); tb.insub[tb.list[i]] = 1; }
+    for (int i = 0; i < nb; ++i) { int lf = tb.list.get(i); tb.binB.set(lf, (int16_t)(nl + i)); tb.insub.set(lf, 1); }
     pr->nbB = nb; pr->status = 1;
   } else {
     pr->type = MOVE_CHANGE;
     int g = tv_list_not_bottom(cur, tb.list);
     if (g == 0) return 0;
-    int nd = tb.list[r_unif_int(rng, 0, g)];
+    int nd = tb.list.get(r_unif_int(rng, 0, g));
     pr->node = nd;
     int v = tv_draw_var(cur, m, nd, rng);
     pr->var = v;
     int lo, hi; tv_interval(cur, m, nd, v, lo, hi);
     int lmn = 1 << 30, lmx = -1, rmn = 1 << 30, rmx = -1;
-    tv_min_max_split(cur, cur.left[nd], v, lmn, lmx);
-    tv_min_max_split(cur, cur.right[nd], v, rmn, rmx);
+    tv_min_max_split(cur, cur.left.get(nd), v, lmn, lmx);
+    tv_min_max_split(cur, cur.right.get(nd), v, rmn, rmx);
     if (lmx >= 0 && lmx + 1 > lo) lo = lmx + 1;
     if (rmx >= 0 && rmn - 1 < hi) hi = rmn - 1;
     if (hi < lo) return 0;
     int s = r_unif_int(rng, lo, hi + 1);
     pr->split = s;
-    pt.var[nd] = (int16_t)v; pt.cut[nd] = (uint16_t)s;
+    pt.var.set(nd, (int16_t)v); pt.cut.set(nd, (uint16_t)s);
+    tv_fill_info(pt, m, nd);
     pr->XLogPi = tv_log_prior(cur, m);
     pr->YLogPi = tv_log_prior(pt, m);
     int nb = tv_list_leaves(pt, nd, tb.list);
-    for (int i = 0; i < nb; ++i) { tb.binB[tb.list[i]] = (int16_t)(nl + i); tb.insub[tb.list[i]] = 1; }
+    for (int i = 0; i < nb; ++i) { int lf = tb.list.get(i); tb.binB.set(lf, (int16_t)(nl + i)); tb.insub.set(lf, 1); }
     pr->nbB = nb; pr->status = 1;
   }
   return 0;
@@ -354,88 +456,106 @@ S4B_HD inline double leaf_loglik(double cnt, double sum, double sigma2, double p
   return 0.5 * log(prec / (prec + dataPrec)) + 0.5 * (sb * sb) / (prec + dataPrec);
 }
 
+S4B_HD inline double draw_leaf(double lc, double ls, double sigma2, double prec, MTState* rng) {
+  double postPrec = lc / sigma2;
+  double mean = postPrec * (ls / lc) / (prec + postPrec);
+  double sd = 1.0 / sqrt(prec + postPrec);
+  return mean + sd * r_norm(rng);
+}
+
+// batched math (defaults: element by element; the wave policy overloads them lane-parallel)
+template <class ABIN, class AOUT>
+S4B_HD inline void bins_loglik(const ABIN& binCnt, const ABIN& binSum, int nb, double sigma2, double prec, AOUT& out) {
+  for (int b = 0; b < nb; ++b) { double c = binCnt.get(b); out.set(b, c == 0.0 ? 0.0 : leaf_loglik(c, binSum.get(b), sigma2, prec)); }
+}
+// leaf i (DFS rank): value from its sufficient statistics and the two uniforms drawn for it
+template <class AF64>
+S4B_HD inline void leaves_draw(const AF64& lc, const AF64& ls, const AF64& u1, const AF64& u2, int nl, double sigma2, double prec, AF64& out) {
+  for (int i = 0; i < nl; ++i) {
+    double c = lc.get(i);
+    if (c == 0.0) { out.set(i, 0.0); continue; }
+    const double BIG = 134217728.0;
+    double z = r_qnorm(((double)(int)(BIG * u1.get(i)) + u2.get(i)) / BIG);
+    double postPrec = c / sigma2;
+    double mean = postPrec * (ls.get(i) / c) / (prec + postPrec);
+    double sd = 1.0 / sqrt(prec + postPrec);
+    out.set(i, mean + sd * z);
+  }
+}
+
 // Consumes the bins of the pending proposal: accept/reject, update the tree (cur, mu, cnt), draw the
 // leaf parameters.  muOld receives the pre-update leaf values by old node id (the apply kernel needs
 // them); tb.insub keeps the "re-route" flags for the apply kernel.  Returns the new hwm.
-S4B_HD inline int decide(const TreeView& cur, double* mu, int32_t* cnt, double* muOld, int hwm, const ModelView& m,
-                         double sigma, MTState* rng, Proposal* pr, const StepTables& tb,
-                         const double* binCnt, const double* binSum, int32_t* accepted, StepRecord* rec) {
-  const TreeView& pt = tb.prop;
+// work arrays of decide(): nb (<= bin capacity) log-likelihoods, per-leaf stats / uniforms / values
+template <class AF64>
+struct DecideWork { AF64 ll, lc, ls, u1, u2, val; };
+
+template <class TR, class TBL, class AF64, class AI32, class ABIN>
+S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, const ModelView& m, double sigma, MTState* rng,
+                         const Proposal* pr, TBL& tb, const ABIN& binCnt, const ABIN& binSum, DecideWork<AF64>& wk,
+                         int32_t* accepted, StepRecord* rec) {
+  TR& pt = tb.prop;
+  sigma = S4B_UNI(sigma);
   const double sigma2 = sigma * sigma;
   int acc = 0;
-  for (int i = 0; i < pr->hwm; ++i) muOld[i] = (i < hwm) ? mu[i] : 0.0;
-  if (pr->status == 1) {
-    const int nd = pr->node;
+  const int prHwm = S4B_UNI(pr->hwm), prType = S4B_UNI(pr->type), prStatus = S4B_UNI(pr->status), prNode = S4B_UNI(pr->node);
+  for (int i = 0; i < prHwm; ++i) muOld.set(i, (i < hwm) ? mu.get(i) : 0.0);
+  const int nbAll = S4B_UNI(pr->nbA) + S4B_UNI(pr->nbB);
+  if (prStatus == 1) {
+    const int nd = prNode;
+    bins_loglik(binCnt, binSum, nbAll, sigma2, m.leafPrec, wk.ll);
     double oldLL = 0.0, newLL = 0.0; bool oldEmpty = false, newEmpty = false;
-    // old branch: current leaves under nd, in DFS order
-    int no = tv_list_leaves(cur, nd, tb.list);
+    int no = tv_list_leaves(cur, nd, tb.list);   // old branch: current leaves under nd, DFS order
     for (int i = 0; i < no; ++i) {
-      int b = tb.binA[tb.list[i]];
-      if (binCnt[b] == 0.0) oldEmpty = true; else oldLL += leaf_loglik(binCnt[b], binSum[b], sigma2, m.leafPrec);
+      int b = tb.binA.get(tb.list.get(i));
+      if (binCnt.get(b) == 0.0) oldEmpty = true; else oldLL += wk.ll.get(b);
     }
-    if (pr->type == MOVE_DEATH) {
-      int bl = tb.binA[cur.left[nd]], br = tb.binA[cur.right[nd]];
-      double c = binCnt[bl] + binCnt[br], s = binSum[bl] + binSum[br];
+    if (prType == MOVE_DEATH) {
+      int bl = tb.binA.get(cur.left.get(nd)), br = tb.binA.get(cur.right.get(nd));
+      double c = binCnt.get(bl) + binCnt.get(br), s = binSum.get(bl) + binSum.get(br);
       if (c == 0.0) newEmpty = true; else newLL = leaf_loglik(c, s, sigma2, m.leafPrec);
     } else {
       int nn = tv_list_leaves(pt, nd, tb.list);
       for (int i = 0; i < nn; ++i) {
-        int b = tb.binB[tb.list[i]];
-        if (binCnt[b] == 0.0) newEmpty = true; else newLL += leaf_loglik(binCnt[b], binSum[b], sigma2, m.leafPrec);
+        int b = tb.binB.get(tb.list.get(i));
+        if (binCnt.get(b) == 0.0) newEmpty = true; else newLL += wk.ll.get(b);
       }
     }
     if (oldEmpty) oldLL = -10000000.0;
     if (newEmpty) newLL = -10000000.0;
     double ratio;
-    if (pr->type == MOVE_BIRTH || pr->type == MOVE_DEATH) ratio = pr->priorRatio * exp(newLL - oldLL) * pr->transRatio;
-    else ratio = exp(pr->YLogPi + newLL - pr->XLogPi - oldLL);
-    acc = (r_unif(rng) < ratio) ? 1 : 0;
+    if (prType == MOVE_BIRTH || prType == MOVE_DEATH) ratio = S4B_UNI(pr->priorRatio) * exp(newLL - oldLL) * S4B_UNI(pr->transRatio);
+    else ratio = exp(S4B_UNI(pr->YLogPi) + newLL - S4B_UNI(pr->XLogPi) - oldLL);
+    acc = (r_unif(rng) < S4B_UNI(ratio)) ? 1 : 0;
   }
-  // leaf statistics of the tree we end up with, by node id
-  // (re-uses tb.list as the DFS leaf list of the final tree)
-  if (acc) {
-    if (pr->type == MOVE_DEATH) {
-      const int nd = pr->node;
-      int L = cur.left[nd], R = cur.right[nd];
-      int bl = tb.binA[L], br = tb.binA[R];
-      // fold the two children into the parent's A bin slot `bl`
-      double c = binCnt[bl] + binCnt[br], s = binSum[bl] + binSum[br];
-      tb.insub[L] = 1; tb.insub[R] = 1;
-      tv_copy(pt, cur, pr->hwm);
-      int nl = tv_list_leaves(cur, 0, tb.list);
-      for (int i = 0; i < nl; ++i) {
-        int n = tb.list[i];
-        double lc, ls;
-        if (n == nd) { lc = c; ls = s; } else { int b = tb.binA[n]; lc = binCnt[b]; ls = binSum[b]; }
-        cnt[n] = (int32_t)lc;
-        if (lc == 0.0) { mu[n] = 0.0; continue; }
-        double postPrec = lc / sigma2;
-        double mean = postPrec * (ls / lc) / (m.leafPrec + postPrec);
-        double sd = 1.0 / sqrt(m.leafPrec + postPrec);
-        mu[n] = mean + sd * r_norm(rng);
-      }
-      hwm = pr->hwm;
-      // (freed slots keep hwm; tv_alloc reuses them)
-      if (rec) { rec->type = pr->type; rec->status = 1; rec->var = pr->var; rec->split = pr->split; rec->numLeaves = nl; }
-      *accepted = 1;
-      return hwm;
-    }
-    tv_copy(pt, cur, pr->hwm);
-    hwm = pr->hwm;
+  // sufficient statistics of every leaf of the tree we end up with, in DFS order; the uniforms of the leaf
+  // draws are consumed in that order, the (expensive) quantile / posterior arithmetic is batched afterwards
+  const bool deathAcc = acc && prType == MOVE_DEATH;
+  const int nd = prNode;
+  double cDeath = 0.0, sDeath = 0.0;
+  if (deathAcc) {
+    int L = cur.left.get(nd), R = cur.right.get(nd);
+    int bl = tb.binA.get(L), br = tb.binA.get(R);
+    cDeath = binCnt.get(bl) + binCnt.get(br); sDeath = binSum.get(bl) + binSum.get(br);
+    tb.insub.set(L, 1); tb.insub.set(R, 1);
   }
-  int nl = tv_list_leaves(cur, 0, tb.list);
+  if (acc) { tv_copy(pt, cur, prHwm); hwm = prHwm; }
+  const int nl = tv_list_leaves(cur, 0, tb.list);
   for (int i = 0; i < nl; ++i) {
-    int n = tb.list[i];
-    int b = (acc && tb.binB[n] >= 0) ? tb.binB[n] : tb.binA[n];
-    double lc = binCnt[b], ls = binSum[b];
-    cnt[n] = (int32_t)lc;
-    if (lc == 0.0) { mu[n] = 0.0; continue; }
-    double postPrec = lc / sigma2;
-    double mean = postPrec * (ls / lc) / (m.leafPrec + postPrec);
-    double sd = 1.0 / sqrt(m.leafPrec + postPrec);
-    mu[n] = mean + sd * r_norm(rng);
+    int n = tb.list.get(i);
+    double lc, ls;
+    if (deathAcc && n == nd) { lc = cDeath; ls = sDeath; }
+    else {
+      int bB = tb.binB.get(n);
+      int b = (acc && !deathAcc && bB >= 0) ? bB : (int)tb.binA.get(n);
+      lc = binCnt.get(b); ls = binSum.get(b);
+    }
+    wk.lc.set(i, lc); wk.ls.set(i, ls);
+    if (lc != 0.0) { wk.u1.set(i, r_unif(rng)); wk.u2.set(i, r_unif(rng)); }
   }
-  if (rec) { rec->type = pr->type; rec->status = pr->status == 1 ? acc : -1; rec->var = pr->var; rec->split = pr->split; rec->numLeaves = nl; }
+  leaves_draw(wk.lc, wk.ls, wk.u1, wk.u2, nl, sigma2, m.leafPrec, wk.val);
+  for (int i = 0; i < nl; ++i) { int n = tb.list.get(i); cnt.set(n, (int32_t)wk.lc.get(i)); mu.set(n, wk.val.get(i)); }
+  if (rec) { rec->type = prType; rec->status = prStatus == 1 ? acc : -1; rec->var = pr->var; rec->split = pr->split; rec->numLeaves = nl; }
   *accepted = acc;
   return hwm;
 }

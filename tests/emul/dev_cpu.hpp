@@ -36,6 +36,8 @@ class DevCpu {
       sc_[s].pvar.assign((size_t)nc_, 0); sc_[s].pleft.assign((size_t)nc_, 0); sc_[s].pright.assign((size_t)nc_, 0); sc_[s].pparent.assign((size_t)nc_, 0);
       sc_[s].pcut.assign((size_t)nc_, 0); sc_[s].binA.assign((size_t)nc_, 0); sc_[s].binB.assign((size_t)nc_, 0); sc_[s].list.assign((size_t)nc_, 0);
       sc_[s].insub.assign((size_t)nc_, 0); sc_[s].muOld.assign((size_t)nc_, 0.0);
+      sc_[s].cna.assign((size_t)nc_, 0); sc_[s].cdep.assign((size_t)nc_, 0); sc_[s].pna.assign((size_t)nc_, 0); sc_[s].pdep.assign((size_t)nc_, 0);
+      sc_[s].work.assign((size_t)12 * nc_, 0.0);
     }
     binCnt_.assign((size_t)2 * nc_, 0.0); binSum_.assign((size_t)2 * nc_, 0.0);
     trace_.assign((size_t)d.traceCap, StepRecord{});
@@ -52,6 +54,7 @@ class DevCpu {
       c.pvar = sc_[s].pvar.data(); c.pleft = sc_[s].pleft.data(); c.pright = sc_[s].pright.data(); c.pparent = sc_[s].pparent.data(); c.pcut = sc_[s].pcut.data();
       c.binA = sc_[s].binA.data(); c.binB = sc_[s].binB.data(); c.list = sc_[s].list.data(); c.insub = sc_[s].insub.data(); c.muOld = sc_[s].muOld.data();
       c.prop = &sc_[s].prop; c.accepted = &sc_[s].accepted;
+      c.cna = sc_[s].cna.data(); c.cdep = sc_[s].cdep.data(); c.pna = sc_[s].pna.data(); c.pdep = sc_[s].pdep.data(); c.work = sc_[s].work.data();
     }
     a_.partCnt = nullptr; a_.partSum = nullptr; a_.binCnt = binCnt_.data(); a_.binSum = binSum_.data();
     a_.rng = &rng_; a_.scale = &scale_; a_.numCuts = numCuts_.data();
@@ -137,7 +140,7 @@ class DevCpu {
       TreeView tv = tree_view(a_, t);
       for (size_t i = 0; i < n_; ++i) {
         int nd = 0;
-        while (tv.var[nd] >= 0) nd = (xbin_[(size_t)tv.var[nd] * n_ + i] <= tv.cut[nd]) ? tv.left[nd] : tv.right[nd];
+        while (tv.var.get(nd) >= 0) nd = (xbin_[(size_t)tv.var.get(nd) * n_ + i] <= tv.cut.get(nd)) ? tv.left.get(nd) : tv.right.get(nd);
         leaf_[(size_t)t * n_ + i] = (uint16_t)nd;
         R_[i] -= mu_[(size_t)t * nc_ + nd];
       }
@@ -160,7 +163,7 @@ class DevCpu {
       for (int t = 0; t < T_; ++t) {
         TreeView tv = tree_view(a_, t);
         int nd = 0;
-        while (tv.var[nd] >= 0) nd = (xbinTest_[(size_t)tv.var[nd] * nTest_ + i] <= tv.cut[nd]) ? tv.left[nd] : tv.right[nd];
+        while (tv.var.get(nd) >= 0) nd = (xbinTest_[(size_t)tv.var.get(nd) * nTest_ + i] <= tv.cut.get(nd)) ? tv.left.get(nd) : tv.right.get(nd);
         f += mu_[(size_t)t * nc_ + nd];
       }
       out[i] = (f + 0.5) * scale_.range + scale_.min;
@@ -235,14 +238,14 @@ class DevCpu {
       int lf = leaf[i], nl = lf;
       if (acc && c.insub[lf]) {
         int nd = pr.node;
-        while (tv.var[nd] >= 0) nd = (xbin_[(size_t)tv.var[nd] * n_ + i] <= tv.cut[nd]) ? tv.left[nd] : tv.right[nd];
+        while (tv.var.get(nd) >= 0) nd = (xbin_[(size_t)tv.var.get(nd) * n_ + i] <= tv.cut.get(nd)) ? tv.left.get(nd) : tv.right.get(nd);
         nl = nd; leaf[i] = (uint16_t)nd;
       }
       R_[i] = (R_[i] + c.muOld[lf]) - mu[nl];
     }
   }
 
-  struct Scratch { std::vector<int16_t> pvar, pleft, pright, pparent, binA, binB, list; std::vector<uint16_t> pcut; std::vector<uint8_t> insub;
+  struct Scratch { std::vector<int16_t> pvar, pleft, pright, pparent, binA, binB, list, cna, cdep, pna, pdep; std::vector<double> work; std::vector<uint16_t> pcut; std::vector<uint8_t> insub;
                    std::vector<double> muOld; Proposal prop; int32_t accepted = 0; };
   DevInit di_;
   size_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0;
