@@ -22,7 +22,7 @@ struct StepScratch {
   int16_t *pvar, *pleft, *pright, *pparent; uint16_t* pcut;
   int16_t *binA, *binB, *list; uint8_t* insub;
   double* muOld; Proposal* prop; int32_t* accepted;
-  int16_t *cna, *cdep, *pna, *pdep;   // node memos of the current / proposed tree (pointer path)
+  int16_t *pna, *pdep;                // node memo of the proposed tree (pointer path)
   double* work;                       // [6][2 nc] decide() work arrays (pointer path)
 };
 
@@ -44,6 +44,9 @@ struct BartArrays {
   uint16_t* leaf;              // [T][npad] node id of the leaf holding observation i in tree t
   // trees, [T][nc]
   int16_t *var, *left, *right, *parent; uint16_t* cut; double* mu; int32_t* cnt; int32_t* hwm;
+  // per-tree structure cache, [T][nc] / [T]: node memo (available predictors, depth), leaves in DFS order,
+  // internal nodes in pre- and post-order, log tree prior; rebuilt lazily after an accepted move
+  int16_t *cna, *cdep, *cleaf, *cpre, *cpost; int32_t *cnl, *cni, *cvalid; double* clogpi;
   // updates in flight: two scratch sets, tree t uses set (t & 1) so that the proposal of tree t+1 can be
   // drawn (same lane, same RNG stream position) while the apply pass of tree t still reads its tables
   StepScratch sc[2];
@@ -57,8 +60,13 @@ struct BartArrays {
 
 S4B_HD inline TreeView tree_view(const BartArrays& a, int t) {
   size_t o = (size_t)t * (size_t)a.nc;
-  const StepScratch& c = a.sc[t & 1];
-  return make_tree_view(a.var + o, a.cut + o, a.left + o, a.right + o, a.parent + o, a.nc, c.cna, c.cdep);
+  return make_tree_view(a.var + o, a.cut + o, a.left + o, a.right + o, a.parent + o, a.nc, a.cna + o, a.cdep + o);
+}
+S4B_HD inline TreeCache tree_cache(const BartArrays& a, int t) {
+  size_t o = (size_t)t * (size_t)a.nc;
+  TreeCache c; c.leaf = PtrArr<int16_t>(a.cleaf + o); c.pre = PtrArr<int16_t>(a.cpre + o); c.post = PtrArr<int16_t>(a.cpost + o);
+  c.nl = a.cnl[t]; c.ni = a.cni[t]; c.logPi = a.clogpi[t]; c.valid = a.cvalid[t];
+  return c;
 }
 S4B_HD inline StepTables step_tables(const BartArrays& a, int t) {
   const StepScratch& c = a.sc[t & 1];
@@ -74,10 +82,11 @@ S4B_HD inline void propose_step(const BartArrays& a, int t) {
   TreeView cur = tree_view(a, t);
   StepTables tb = step_tables(a, t);
   const int hwm = a.hwm[t];
-  tv_fill_info(cur, a.model, 0);
+  TreeCache ca = tree_cache(a, t);
+  if (!ca.valid) { tv_rebuild_cache(cur, a.model, ca); a.cnl[t] = ca.nl; a.cni[t] = ca.ni; a.clogpi[t] = ca.logPi; a.cvalid[t] = 1; }
   tv_copy(cur, tb.prop, hwm);
   for (int i = 0; i < hwm; ++i) { tb.binA.set(i, -1); tb.binB.set(i, -1); tb.insub.set(i, 0); }
-  if (propose(cur, hwm, a.model, a.rng, a.sc[t & 1].prop, tb) != 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
+  if (propose(cur, hwm, a.model, a.rng, a.sc[t & 1].prop, tb, ca) != 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
 }
 S4B_HD inline void push_trace(const BartArrays& a, const StepRecord& rec) {
   int k = *a.traceCount;
@@ -94,8 +103,9 @@ S4B_HD inline void control_step(const BartArrays& a, int t, int proposeNext) {
   wk.ll = PtrArr<double>(c.work); wk.lc = PtrArr<double>(c.work + ws); wk.ls = PtrArr<double>(c.work + 2 * ws);
   wk.u1 = PtrArr<double>(c.work + 3 * ws); wk.u2 = PtrArr<double>(c.work + 4 * ws); wk.val = PtrArr<double>(c.work + 5 * ws);
   StepRecord rec;
+  TreeCache ca = tree_cache(a, t);
   a.hwm[t] = decide(cur, mu, cnt, muOld, a.hwm[t], a.model, a.scale->sigma, a.rng, c.prop, tb, binCnt, binSum, wk, c.accepted,
-                    a.traceOn ? &rec : nullptr);
+                    a.traceOn ? &rec : nullptr, a.cvalid + t, ca);
   if (a.traceOn) push_trace(a, rec);
   if (proposeNext >= 0) propose_step(a, proposeNext);
 }

@@ -74,24 +74,70 @@ __device__ __forceinline__ StatsTables carve_stats(unsigned char* base, int nc) 
   s.insub = (uint8_t*)base;
   return s;
 }
-static size_t stats_lds_bytes(int nc) { return ((size_t)nc * (8 + 6 * 2 + 1) + 15) / 16 * 16 + 2 * 4 * NBMAX * 8; }
+__host__ __device__ static inline size_t stats_lds_bytes(int nc) { return ((size_t)nc * (8 + 6 * 2 + 1) + 15) / 16 * 16 + 2 * 4 * NBMAX * 8; }
 
-template <int NB>
-__device__ __forceinline__ void stats_pass(const BartArrays& a, int t, const StatsTables& L, int root, int base, int nbTotal,
-                                           double* redS, double* redN) {
+// tables of the apply half (tree t-1): leaf values before / after its update, its (new) structure and the
+// leaves whose observations must be re-routed
+struct ApplyTables { double* muOld; double* muNew; int16_t* var; uint16_t* cut; int16_t* left; int16_t* right; uint8_t* insub; };
+__device__ __forceinline__ ApplyTables carve_apply(unsigned char* base, int nc) {
+  ApplyTables p;
+  p.muOld = (double*)base; base += (size_t)nc * 8;
+  p.muNew = (double*)base; base += (size_t)nc * 8;
+  p.var = (int16_t*)base; base += (size_t)nc * 2;
+  p.cut = (uint16_t*)base; base += (size_t)nc * 2;
+  p.left = (int16_t*)base; base += (size_t)nc * 2;
+  p.right = (int16_t*)base; base += (size_t)nc * 2;
+  p.insub = (uint8_t*)base;
+  return p;
+}
+static size_t apply_lds_bytes(int nc) { return ((size_t)nc * 25 + 15) / 16 * 16; }
+static size_t tree_lds_bytes(int nc) { return stats_lds_bytes(nc) + apply_lds_bytes(nc); }
+
+// One pass over the observations for tree t.  APPLY: first finish tree t-1 (R_i += mu_old - mu_new, relabel
+// the observations under its accepted move) — the residual is then read once and written once per tree
+// update.  Then accumulate the (count, sum) bins [base, base + NB) of tree t's pending proposal.
+template <int NB, bool APPLY>
+__device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const StatsTables& L, const ApplyTables& Q, int root, int prevRoot,
+                                          int prevAcc, int base, int nbTotal, double* redS, double* redN) {
   double accS[NB], accN[NB];
 #pragma unroll
   for (int k = 0; k < NB; ++k) { accS[k] = 0.0; accN[k] = 0.0; }
   const int64_t nQuads = (a.n + 3) >> 2;
   const uint16_t* __restrict__ leafPlane = a.leaf + (size_t)t * a.npad;
-  const double* __restrict__ R = a.R;
+  uint16_t* __restrict__ prevPlane = a.leaf + (size_t)(t > 0 ? t - 1 : 0) * a.npad;
+  double* __restrict__ R = a.R;
   for (int64_t qd = (int64_t)blockIdx.x * BLOCK + threadIdx.x; qd < nQuads; qd += (int64_t)gridDim.x * BLOCK) {
     const int64_t i0 = qd << 2;
     const double2 r01 = *reinterpret_cast<const double2*>(R + i0);
     const double2 r23 = *reinterpret_cast<const double2*>(R + i0 + 2);
     const ushort4 lf4 = *reinterpret_cast<const ushort4*>(leafPlane + i0);
-    const double rr[4] = {r01.x, r01.y, r23.x, r23.y};
+    double rr[4] = {r01.x, r01.y, r23.x, r23.y};
     const unsigned lf[4] = {lf4.x, lf4.y, lf4.z, lf4.w};
+    if (APPLY) {
+      const ushort4 pl4 = *reinterpret_cast<const ushort4*>(prevPlane + i0);
+      unsigned pl[4] = {pl4.x, pl4.y, pl4.z, pl4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (i0 + e >= a.n) break;
+        const unsigned l = pl[e];
+        unsigned nl = l;
+        if (prevAcc && Q.insub[l]) {
+          int nd = prevRoot;
+          int v = Q.var[nd];
+          while (v >= 0) {
+            const unsigned x = a.xbin[(size_t)v * a.npad + (size_t)(i0 + e)];
+            nd = (x <= (unsigned)Q.cut[nd]) ? Q.left[nd] : Q.right[nd];
+            v = Q.var[nd];
+          }
+          nl = (unsigned)nd;
+        }
+        rr[e] = (rr[e] + Q.muOld[l]) - Q.muNew[nl];
+        pl[e] = nl;
+      }
+      *reinterpret_cast<double2*>(R + i0) = make_double2(rr[0], rr[1]);
+      *reinterpret_cast<double2*>(R + i0 + 2) = make_double2(rr[2], rr[3]);
+      if (prevAcc) *reinterpret_cast<ushort4*>(prevPlane + i0) = make_ushort4((unsigned short)pl[0], (unsigned short)pl[1], (unsigned short)pl[2], (unsigned short)pl[3]);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (i0 + e >= a.n) break;
@@ -135,23 +181,41 @@ __device__ __forceinline__ void stats_pass(const BartArrays& a, int t, const Sta
   __syncthreads();
 }
 
-__global__ __launch_bounds__(BLOCK) void k_stats(BartArrays a, int t) {
+// k_tree<APPLY>: the O(N) kernel of one tree update.  APPLY = false for the first tree of a sweep.
+template <bool APPLY>
+__global__ __launch_bounds__(BLOCK) void k_tree(BartArrays a, int t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const StepScratch& c = a.sc[t & 1];
   const Proposal pr = *c.prop;
   StatsTables L = carve_stats(smem, a.nc);
   double* redS = (double*)(smem + ((size_t)a.nc * 21 + 15) / 16 * 16);
   double* redN = redS + 4 * NBMAX;
+  ApplyTables Q = carve_apply(smem + stats_lds_bytes(a.nc), a.nc);
   const double* mu = a.mu + (size_t)t * a.nc;
   for (int i = threadIdx.x; i < pr.hwm; i += BLOCK) {
     L.mu[i] = mu[i]; L.binA[i] = c.binA[i]; L.binB[i] = c.binB[i]; L.pvar[i] = c.pvar[i]; L.pcut[i] = c.pcut[i];
     L.pleft[i] = c.pleft[i]; L.pright[i] = c.pright[i]; L.insub[i] = c.insub[i];
   }
+  int prevAcc = 0, prevRoot = 0;
+  if (APPLY) {
+    const StepScratch& cp = a.sc[(t - 1) & 1];
+    prevAcc = *cp.accepted; prevRoot = cp.prop->node;
+    const int hp = cp.prop->hwm > a.hwm[t - 1] ? cp.prop->hwm : a.hwm[t - 1];
+    const size_t o = (size_t)(t - 1) * a.nc;
+    for (int i = threadIdx.x; i < hp; i += BLOCK) {
+      Q.muOld[i] = cp.muOld[i]; Q.muNew[i] = a.mu[o + i]; Q.var[i] = a.var[o + i]; Q.cut[i] = a.cut[o + i]; Q.left[i] = a.left[o + i];
+      Q.right[i] = a.right[o + i]; Q.insub[i] = cp.insub[i];
+    }
+  }
   __syncthreads();
   const int nb = pr.nbA + pr.nbB;
-  if (nb <= 4) stats_pass<4>(a, t, L, pr.node, 0, nb, redS, redN);
-  else if (nb <= 8) stats_pass<8>(a, t, L, pr.node, 0, nb, redS, redN);
-  else for (int base = 0; base < nb; base += NBMAX) stats_pass<NBMAX>(a, t, L, pr.node, base, nb, redS, redN);
+  if (nb <= 4) tree_pass<4, APPLY>(a, t, L, Q, pr.node, prevRoot, prevAcc, 0, nb, redS, redN);
+  else if (nb <= 8) tree_pass<8, APPLY>(a, t, L, Q, pr.node, prevRoot, prevAcc, 0, nb, redS, redN);
+  else {
+    tree_pass<NBMAX, APPLY>(a, t, L, Q, pr.node, prevRoot, prevAcc, 0, nb, redS, redN);
+    // further bin passes read the residual this thread has just written
+    for (int base = NBMAX; base < nb; base += NBMAX) tree_pass<NBMAX, false>(a, t, L, Q, pr.node, prevRoot, prevAcc, base, nb, redS, redN);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -237,6 +301,8 @@ __device__ __attribute__((noinline)) void control_global_path(BartArrays a, int 
 
 static size_t control_lds_bytes(int P, int logIntLen) { return ((size_t)P * 4 + 15) / 16 * 16 + (size_t)logIntLen * 8 + 64; }
 
+typedef TreeCacheT<WaveArr<int16_t>> WaveCache;
+
 __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ MTState s_rng;
@@ -245,16 +311,61 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
   __shared__ double s_red[2][BLOCK / 64][64];
   __shared__ Proposal s_prT, s_prN;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  S4B_TICK(c0);
-  const bool doDecide = t >= 0;
-  const StepScratch& cT = a.sc[(doDecide ? t : 0) & 1];
-  const StepScratch& cN = a.sc[(next >= 0 ? next : 0) & 1];
-  // every thread derives the path from the same few words (no flag, no extra barrier)
-  int need = 0, nb = 0, hwmT = 0, hwmN = 0;
-  Proposal prT;
-  if (doDecide) { prT = *cT.prop; hwmT = a.hwm[t]; need = prT.hwm > hwmT ? prT.hwm : hwmT; nb = prT.nbA + prT.nbB; }
-  if (next >= 0) { hwmN = a.hwm[next]; if (hwmN + 2 > need) need = hwmN + 2; }
-  const bool wavePath = need <= 64 && nb <= 64;
+  const bool doDecide = t >= 0, doPropose = next >= 0;
+  const int tt = doDecide ? t : 0, tn = doPropose ? next : 0;
+  const StepScratch& cT = a.sc[tt & 1];
+  const StepScratch& cN = a.sc[tn & 1];
+  const int nc = a.nc;
+  const size_t oT = (size_t)tt * nc, oN = (size_t)tn * nc;
+  const bool laneIn = lane < nc;
+  const int li = laneIn ? lane : 0;
+
+  // ---- hop 1: every global load of the step is issued up front, none depends on another -----------------
+  Proposal prT = *cT.prop;
+  const int hwmT = a.hwm[tt], hwmN = a.hwm[tn];
+  const int cvalidT = a.cvalid[tt], cvalidN = a.cvalid[tn];
+  const int cnlT = a.cnl[tt], cnlN = a.cnl[tn], cniN = a.cni[tn];
+  const double clogpiN = a.clogpi[tn];
+  const double sigma = a.scale->sigma;
+  // wave 0 registers (lane i = node slot i / list position i); harmless for the other waves
+  WaveTree curT, curN; WaveTables tbT, tbN; WaveCache caT, caN;
+  WaveArrD mu, muOld; WaveArr<int32_t> cnt;
+  curT.var.r = a.var[oT + li]; curT.cut.r = a.cut[oT + li]; curT.left.r = a.left[oT + li]; curT.right.r = a.right[oT + li];
+  curT.parent.r = a.parent[oT + li]; curT.na.r = a.cna[oT + li]; curT.dep.r = a.cdep[oT + li]; curT.nc = nc < 64 ? nc : 64;
+  tbT.prop.var.r = cT.pvar[li]; tbT.prop.cut.r = cT.pcut[li]; tbT.prop.left.r = cT.pleft[li]; tbT.prop.right.r = cT.pright[li];
+  tbT.prop.parent.r = cT.pparent[li]; tbT.prop.na.r = cT.pna[li]; tbT.prop.dep.r = cT.pdep[li]; tbT.prop.nc = curT.nc;
+  tbT.binA.r = cT.binA[li]; tbT.binB.r = cT.binB[li]; tbT.insub.r = cT.insub[li]; tbT.list.r = 0;
+  caT.leaf.r = a.cleaf[oT + li]; caT.pre.r = 0; caT.post.r = 0; caT.nl = cnlT; caT.ni = 0; caT.logPi = 0.0; caT.valid = cvalidT;
+  mu.load(a.mu[oT + li]); muOld.load(0.0); cnt.r = a.cnt[oT + li];
+  curN.var.r = a.var[oN + li]; curN.cut.r = a.cut[oN + li]; curN.left.r = a.left[oN + li]; curN.right.r = a.right[oN + li];
+  curN.parent.r = a.parent[oN + li]; curN.na.r = a.cna[oN + li]; curN.dep.r = a.cdep[oN + li]; curN.nc = curT.nc;
+  caN.leaf.r = a.cleaf[oN + li]; caN.pre.r = a.cpre[oN + li]; caN.post.r = a.cpost[oN + li];
+  caN.nl = cnlN; caN.ni = cniN; caN.logPi = clogpiN; caN.valid = cvalidN;
+  // partials of the first 8 bins (whether or not the proposal has that many: the grid-sized slabs exist)
+  double ps[8], pc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ps[j] = 0.0; pc[j] = 0.0; }
+  if (doDecide) {
+    for (int b = threadIdx.x; b < a.grid; b += BLOCK) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ps[j] += a.partSum[(size_t)j * a.grid + b]; pc[j] += a.partCnt[(size_t)j * a.grid + b]; }
+    }
+  }
+  // small shared state -> LDS
+  int32_t* numCuts = (int32_t*)smem;
+  double* logInt = (double*)(smem + ((size_t)a.P * 4 + 15) / 16 * 16);
+  for (int i = threadIdx.x; i < (int)(sizeof(MTState) / 4); i += BLOCK) ((uint32_t*)&s_rng)[i] = ((const uint32_t*)a.rng)[i];
+  for (int i = threadIdx.x; i < a.P; i += BLOCK) numCuts[i] = a.numCuts[i];
+  for (int i = threadIdx.x; i < a.model.logIntLen; i += BLOCK) logInt[i] = a.model.logInt[i];
+  for (int i = threadIdx.x; i < S4B_MAX_DEPTH; i += BLOCK) {
+    s_tab[i] = a.model.pgDepth[i]; s_tab[S4B_MAX_DEPTH + i] = a.model.logPg[i]; s_tab[2 * S4B_MAX_DEPTH + i] = a.model.log1mPg[i];
+  }
+
+  // ---- path selection (uniform over the workgroup) -----------------------------------------------------
+  int need = 0, nb = 0;
+  if (doDecide) { need = prT.hwm > hwmT ? prT.hwm : hwmT; nb = prT.nbA + prT.nbB; }
+  if (doPropose && hwmN + 2 > need) need = hwmN + 2;
+  const bool wavePath = need <= 64 && nb <= 64 && need <= nc + 2;
   if (!wavePath) {   // large tree: sequential code straight on the global arrays
     if (doDecide) {
       for (int k = wv; k < nb; k += BLOCK / 64) {
@@ -269,84 +380,62 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
     if (threadIdx.x == 0) control_global_path(a, t, next, s_scratch);
     return;
   }
-  // ---- stage the small shared state into LDS; all 256 threads cooperate on every bin's partials
-  int32_t* numCuts = (int32_t*)smem;
-  double* logInt = (double*)(smem + ((size_t)a.P * 4 + 15) / 16 * 16);
-  for (int i = threadIdx.x; i < (int)(sizeof(MTState) / 4); i += BLOCK) ((uint32_t*)&s_rng)[i] = ((const uint32_t*)a.rng)[i];
-  for (int i = threadIdx.x; i < a.P; i += BLOCK) numCuts[i] = a.numCuts[i];
-  for (int i = threadIdx.x; i < a.model.logIntLen; i += BLOCK) logInt[i] = a.model.logInt[i];
-  for (int i = threadIdx.x; i < S4B_MAX_DEPTH; i += BLOCK) {
-    s_tab[i] = a.model.pgDepth[i]; s_tab[S4B_MAX_DEPTH + i] = a.model.logPg[i]; s_tab[2 * S4B_MAX_DEPTH + i] = a.model.log1mPg[i];
-  }
   if (doDecide) {
-    for (int k0 = 0; k0 < nb; k0 += 8) {   // all loads of a batch of 8 bins are issued before any reduction
-      double s[8], c[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { s[j] = 0.0; c[j] = 0.0; }
-      for (int b = threadIdx.x; b < a.grid; b += BLOCK) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) if (k0 + j < nb) { s[j] += a.partSum[(size_t)(k0 + j) * a.grid + b]; c[j] += a.partCnt[(size_t)(k0 + j) * a.grid + b]; }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) if (k0 + j < nb) {
-        const double ss = wave_sum(s[j]), cc = wave_sum(c[j]);
-        if (lane == 0) { s_red[0][wv][k0 + j] = ss; s_red[1][wv][k0 + j] = cc; }
-      }
+    for (int j = 0; j < 8; ++j) if (j < nb) {
+      const double ss = wave_sum(ps[j]), cc = wave_sum(pc[j]);
+      if (lane == 0) { s_red[0][wv][j] = ss; s_red[1][wv][j] = cc; }
+    }
+    for (int k = 8; k < nb; ++k) {   // rare: more than 8 bins
+      double s = 0.0, c = 0.0;
+      for (int b = threadIdx.x; b < a.grid; b += BLOCK) { s += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
+      s = wave_sum(s); c = wave_sum(c);
+      if (lane == 0) { s_red[0][wv][k] = s; s_red[1][wv][k] = c; }
     }
     if (threadIdx.x == 0) s_prT = prT;
   }
   __syncthreads();
   if (wv != 0) return;
-  S4B_TICK(c1);
-  // ---- wave 0: wave-uniform control code on register-resident arrays
+
+  // ---- wave 0: wave-uniform control code on register-resident arrays -------------------------------------
   ModelView m = a.model;
   m.numCuts = numCuts; m.pgDepth = s_tab; m.logPg = s_tab + S4B_MAX_DEPTH; m.log1mPg = s_tab + 2 * S4B_MAX_DEPTH; m.logInt = logInt;
   m.scratch = s_scratch;
-  const int nc = a.nc;
   if (doDecide) {
-    const size_t o = (size_t)t * nc;
-    const int cntIn = need;
-    WaveTree cur; WaveTables tb;
-    wave_tree_load(cur, a.var + o, a.cut + o, a.left + o, a.right + o, a.parent + o, hwmT, nc, lane);
-    wave_tree_load(tb.prop, cT.pvar, cT.pcut, cT.pleft, cT.pright, cT.pparent, cntIn, nc, lane);
-    const bool in = lane < cntIn;
-    tb.binA.r = in ? (int)cT.binA[lane] : -1; tb.binB.r = in ? (int)cT.binB[lane] : -1; tb.insub.r = in ? (int)cT.insub[lane] : 0; tb.list.r = 0;
-    WaveArrD mu, muOld, binSum, binCnt; WaveArr<int32_t> cnt;
-    mu.load(lane < hwmT ? a.mu[o + lane] : 0.0); muOld.load(0.0); cnt.r = lane < hwmT ? a.cnt[o + lane] : 0;
+    WaveArrD binSum, binCnt;
     binSum.load(lane < nb ? ((s_red[0][0][lane] + s_red[0][1][lane]) + s_red[0][2][lane]) + s_red[0][3][lane] : 0.0);
     binCnt.load(lane < nb ? ((s_red[1][0][lane] + s_red[1][1][lane]) + s_red[1][2][lane]) + s_red[1][3][lane] : 0.0);
     DecideWork<WaveArrD> wk;
     wk.ll.load(0.0); wk.lc.load(0.0); wk.ls.load(0.0); wk.u1.load(0.5); wk.u2.load(0.5); wk.val.load(0.0);
-    StepRecord rec; int32_t accepted = 0;
-    const int hwmNew = decide(cur, mu, cnt, muOld, hwmT, m, a.scale->sigma, &s_rng, &s_prT, tb, binCnt, binSum, wk, &accepted, &rec);
-    const int cntOut = s_prT.hwm > hwmNew ? s_prT.hwm : hwmNew;
-    wave_tree_store(cur, a.var + o, a.cut + o, a.left + o, a.right + o, a.parent + o, cntOut, lane);
-    if (lane < cntOut) { a.mu[o + lane] = mu.mine(); a.cnt[o + lane] = cnt.r; cT.muOld[lane] = muOld.mine(); cT.insub[lane] = (uint8_t)tb.insub.r; }
+    StepRecord rec; int32_t accepted = 0; int32_t cacheValid = cvalidT;
+    const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &s_rng, &s_prT, tbT, binCnt, binSum, wk, &accepted, &rec, &cacheValid, caT);
+    const int cntOut = prT.hwm > hwmNew ? prT.hwm : hwmNew;
+    wave_tree_store(curT, a.var + oT, a.cut + oT, a.left + oT, a.right + oT, a.parent + oT, cntOut, lane);
+    if (lane < cntOut) { a.mu[oT + lane] = mu.mine(); a.cnt[oT + lane] = cnt.r; cT.muOld[lane] = muOld.mine(); cT.insub[lane] = (uint8_t)tbT.insub.r; }
     if (lane == 0) {
       a.hwm[t] = hwmNew; *cT.accepted = accepted;
+      if (cacheValid != cvalidT) a.cvalid[t] = cacheValid;
       if (a.traceOn) push_trace(a, rec);
     }
   }
-  S4B_TICK(c2);
-  if (next >= 0) {
-    const size_t o = (size_t)next * nc;
-    WaveTree cur; WaveTables tb;
-    wave_tree_load(cur, a.var + o, a.cut + o, a.left + o, a.right + o, a.parent + o, hwmN, nc, lane);
-    tv_fill_info(cur, m, 0);
-    tb.prop = cur;
-    tb.binA.r = -1; tb.binB.r = -1; tb.insub.r = 0; tb.list.r = 0;
-    if (propose(cur, hwmN, m, &s_rng, &s_prN, tb) != 0 && lane == 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
+  if (doPropose) {
+    if (!caN.valid) {   // the tree changed since its lists were built: rebuild memo + lists + log prior, keep them
+      tv_rebuild_cache(curN, m, caN);
+      if (laneIn) { a.cna[oN + lane] = (int16_t)curN.na.r; a.cdep[oN + lane] = (int16_t)curN.dep.r; a.cleaf[oN + lane] = (int16_t)caN.leaf.r;
+                    a.cpre[oN + lane] = (int16_t)caN.pre.r; a.cpost[oN + lane] = (int16_t)caN.post.r; }
+      if (lane == 0) { a.cnl[next] = caN.nl; a.cni[next] = caN.ni; a.clogpi[next] = caN.logPi; a.cvalid[next] = 1; }
+    }
+    tbN.prop = curN;
+    tbN.binA.r = -1; tbN.binB.r = -1; tbN.insub.r = 0; tbN.list.r = 0;
+    if (propose(curN, hwmN, m, &s_rng, &s_prN, tbN, caN) != 0 && lane == 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
     const int cntOut = s_prN.hwm;
-    wave_tree_store(tb.prop, cN.pvar, cN.pcut, cN.pleft, cN.pright, cN.pparent, cntOut, lane);
-    if (lane < cntOut) { cN.binA[lane] = (int16_t)tb.binA.r; cN.binB[lane] = (int16_t)tb.binB.r; cN.insub[lane] = (uint8_t)tb.insub.r; }
+    wave_tree_store(tbN.prop, cN.pvar, cN.pcut, cN.pleft, cN.pright, cN.pparent, cntOut, lane);
+    if (lane < cntOut) { cN.binA[lane] = (int16_t)tbN.binA.r; cN.binB[lane] = (int16_t)tbN.binB.r; cN.insub[lane] = (uint8_t)tbN.insub.r;
+                         cN.pna[lane] = (int16_t)tbN.prop.na.r; cN.pdep[lane] = (int16_t)tbN.prop.dep.r; }
     if (lane == 0) *cN.prop = s_prN;
   }
-  S4B_TICK(c3);
   // ---- RNG state back to global
   for (int i = lane; i < (int)(sizeof(MTState) / 4); i += 64) ((uint32_t*)a.rng)[i] = ((const uint32_t*)&s_rng)[i];
-#ifdef S4B_CONTROL_TIMING
-  if (lane == 0 && doDecide && next >= 0) { long long c4 = wall_clock64(); g_dbg[0] += c1 - c0; g_dbg[1] += c2 - c1; g_dbg[2] += c3 - c2; g_dbg[3] += c4 - c3; g_dbg[4] += 1; }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -400,7 +489,6 @@ __global__ __launch_bounds__(BLOCK) void k_apply(BartArrays a, int t) {
     if (acc) *reinterpret_cast<ushort4*>(leafPlane + i0) = make_ushort4((unsigned short)lf[0], (unsigned short)lf[1], (unsigned short)lf[2], (unsigned short)lf[3]);
   }
 }
-static size_t apply_lds_bytes(int nc) { return (size_t)nc * (16 + 8 + 1) + 16; }
 
 // ------------------------------------------------------------------------------------------------
 // tree initialisation: full traversal for every tree, residual from scratch
@@ -667,6 +755,8 @@ class DevHip {
     const size_t m = (size_t)T_ * nc_;
     a.var = alloc<int16_t>(m); a.left = alloc<int16_t>(m); a.right = alloc<int16_t>(m); a.parent = alloc<int16_t>(m); a.cut = alloc<uint16_t>(m);
     a.mu = alloc<double>(m); a.cnt = alloc<int32_t>(m); a.hwm = alloc<int32_t>((size_t)T_);
+    a.cna = zalloc<int16_t>(m); a.cdep = zalloc<int16_t>(m); a.cleaf = zalloc<int16_t>(m); a.cpre = zalloc<int16_t>(m); a.cpost = zalloc<int16_t>(m);
+    a.cnl = zalloc<int32_t>((size_t)T_); a.cni = zalloc<int32_t>((size_t)T_); a.cvalid = zalloc<int32_t>((size_t)T_); a.clogpi = zalloc<double>((size_t)T_);
     {
       std::vector<int16_t> var(m, NODE_FREE), neg(m, -1); std::vector<int32_t> hwm((size_t)T_, 1);
       for (int t = 0; t < T_; ++t) var[(size_t)t * nc_] = NODE_LEAF;
@@ -680,7 +770,7 @@ class DevHip {
       c.pvar = zalloc<int16_t>(nc_); c.pleft = zalloc<int16_t>(nc_); c.pright = zalloc<int16_t>(nc_); c.pparent = zalloc<int16_t>(nc_); c.pcut = zalloc<uint16_t>(nc_);
       c.binA = zalloc<int16_t>(nc_); c.binB = zalloc<int16_t>(nc_); c.list = zalloc<int16_t>(nc_); c.insub = zalloc<uint8_t>(nc_);
       c.muOld = zalloc<double>(nc_); c.prop = zalloc<Proposal>(1); c.accepted = zalloc<int32_t>(1);
-      c.cna = zalloc<int16_t>(nc_); c.cdep = zalloc<int16_t>(nc_); c.pna = zalloc<int16_t>(nc_); c.pdep = zalloc<int16_t>(nc_); c.work = zalloc<double>((size_t)12 * nc_);
+      c.pna = zalloc<int16_t>(nc_); c.pdep = zalloc<int16_t>(nc_); c.work = zalloc<double>((size_t)12 * nc_);
     }
     a.partCnt = zalloc<double>((size_t)a.binCap * a.grid); a.partSum = zalloc<double>((size_t)a.binCap * a.grid);
     a.binCnt = zalloc<double>((size_t)a.binCap); a.binSum = zalloc<double>((size_t)a.binCap);
@@ -718,10 +808,13 @@ class DevHip {
     if (nTest_) testOut_ = zalloc<double>((size_t)nTest_);
     // ---- launch configuration
     gridN_ = a.grid;   // one launch geometry for every O(N) kernel: the partial buffers are sized by it
-    ldsStats_ = stats_lds_bytes(nc_); ldsApply_ = apply_lds_bytes(nc_); ldsControl_ = control_lds_bytes(P_, d.model.logIntLen);
-    if (ldsStats_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsStats_));
+    ldsStats_ = stats_lds_bytes(nc_); ldsApply_ = apply_lds_bytes(nc_); ldsTree_ = tree_lds_bytes(nc_); ldsControl_ = control_lds_bytes(P_, d.model.logIntLen);
+    if (ldsTree_ > 64 * 1024) {
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
+    }
     if (ldsApply_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsApply_));
-    if (ldsStats_ > 160 * 1024 || ldsApply_ > 160 * 1024) throw std::runtime_error("node_capacity too large for the 160 KiB LDS of a CU");
+    if (ldsTree_ > 160 * 1024) throw std::runtime_error("node_capacity too large for the 160 KiB LDS of a CU");
     // ---- initial scale from the raw response (offset 0), R = yRescaled
     hipLaunchKernelGGL(k_param_mean, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, 0, 0, 0, 1, a_.offNew); ++launches_;
     hipLaunchKernelGGL(k_scale, dim3(1), dim3(BLOCK), 0, stream_, a_, s_, 1, gridN_); ++launches_;
@@ -737,6 +830,7 @@ class DevHip {
     const size_t m = (size_t)T_ * nc_;
     upload(a_.var, var, m); upload(a_.cut, cut, m); upload(a_.left, left, m); upload(a_.right, right, m); upload(a_.parent, parent, m);
     upload(a_.mu, mu, m); upload(a_.hwm, hwm, (size_t)T_);
+    HIP_OK(hipMemsetAsync(a_.cvalid, 0, (size_t)T_ * 4, stream_));   // new trees: structure caches are stale
     sync();
   }
   void download_trees(int16_t* var, uint16_t* cut, int16_t* left, int16_t* right, int16_t* parent, double* mu, int32_t* cnt, int32_t* hwm) {
@@ -784,18 +878,21 @@ class DevHip {
   void assign_leaves_and_residual() { hipLaunchKernelGGL(k_assign_leaves, dim3(gridN_), dim3(BLOCK), 0, stream_, a_); ++launches_; }
   void sweep(int thin) {
     for (int k = 0; k < thin; ++k) {
+      // per tree: one fused O(N) kernel (finish tree t-1, statistics of tree t) + one control kernel
       hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsControl_, stream_, a_, -1, 0); ++launches_;
       for (int t = 0; t < T_; ++t) {
-        hipLaunchKernelGGL(k_stats, dim3(a_.grid), dim3(BLOCK), ldsStats_, stream_, a_, t); ++launches_;
-        hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsControl_, stream_, a_, t, t + 1 < T_ ? t + 1 : -1); ++launches_;
-        hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, t); ++launches_;
+        if (t == 0) hipLaunchKernelGGL(k_tree<false>, dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
+        else hipLaunchKernelGGL(k_tree<true>, dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
+        hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsControl_, stream_, a_, t, t + 1 < T_ ? t + 1 : -1);
+        launches_ += 2;
       }
+      hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, T_ - 1); ++launches_;
     }
   }
   // per-launch HIP-event timing of extra sweeps on the sampler's stream (bench.py roofline leg)
   void profile_sweep(int nSweeps, int thin, double* out) {
-    const int perSweep = 3 * T_ * thin;
-    std::vector<hipEvent_t> ev((size_t)perSweep * 2);
+    const int perSweep = 2 * T_ * thin + thin;
+    std::vector<hipEvent_t> ev((size_t)perSweep * 2 + 4);
     for (auto& e : ev) HIP_OK(hipEventCreate(&e));
     double sum[3] = {0, 0, 0}, cnt[3] = {0, 0, 0};
     const size_t ldsC = ldsControl_;
@@ -805,19 +902,27 @@ class DevHip {
         hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsC, stream_, a_, -1, 0); ++launches_;
         for (int t = 0; t < T_; ++t) {
           HIP_OK(hipEventRecord(ev[e++], stream_));
-          hipLaunchKernelGGL(k_stats, dim3(a_.grid), dim3(BLOCK), ldsStats_, stream_, a_, t);
+          if (t == 0) hipLaunchKernelGGL(k_tree<false>, dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
+          else hipLaunchKernelGGL(k_tree<true>, dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
           HIP_OK(hipEventRecord(ev[e++], stream_));
           HIP_OK(hipEventRecord(ev[e++], stream_));
           hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsC, stream_, a_, t, t + 1 < T_ ? t + 1 : -1);
           HIP_OK(hipEventRecord(ev[e++], stream_));
-          HIP_OK(hipEventRecord(ev[e++], stream_));
-          hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, t);
-          HIP_OK(hipEventRecord(ev[e++], stream_));
-          launches_ += 3;
+          launches_ += 2;
         }
+        HIP_OK(hipEventRecord(ev[e++], stream_));
+        hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, T_ - 1); ++launches_;
+        HIP_OK(hipEventRecord(ev[e++], stream_));
       }
       sync();
-      for (size_t i = 0; i + 1 < e; i += 2) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); int c = (int)((i / 2) % 3); sum[c] += ms * 1000.0; cnt[c] += 1; }
+      for (size_t i = 0; i + 1 < e; i += 2) {
+        float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        const size_t pair = i / 2, perThin = (size_t)2 * T_ + 1, pos = pair % perThin;
+        const bool first = pos == 0;                       // k_tree<false>: no apply half, not representative
+        const int c = pos == perThin - 1 ? 2 : (int)(pos % 2);
+        if (c == 0 && first) continue;
+        sum[c] += ms * 1000.0; cnt[c] += 1;
+      }
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     for (int c = 0; c < 3; ++c) { out[c] = cnt[c] ? sum[c] / cnt[c] : 0.0; out[3 + c] = cnt[c]; }
@@ -914,7 +1019,7 @@ class DevHip {
 
   int device_ = 0; hipStream_t stream_ = nullptr; hipEvent_t evStart_ = nullptr, evStop_ = nullptr;
   int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1;
-  size_t ldsStats_ = 0, ldsApply_ = 0, ldsControl_ = 0;
+  size_t ldsStats_ = 0, ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0;
   BartArrays a_; StanArrays s_;
   std::vector<void*> allocs_;
   double* pinned_ = nullptr; double* testOut_ = nullptr;

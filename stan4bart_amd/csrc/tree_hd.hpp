@@ -281,6 +281,55 @@ template <class TR> S4B_HD inline double tv_log_prior(const TR& t, const ModelVi
   return result;
 }
 
+// own term of node nd (at depth `depth`) in the log tree prior
+template <class TR> S4B_HD inline double tv_log_prior_own(const TR& t, const ModelView& m, int nd, int depth) {
+  int na = tv_num_avail(t, m, nd);
+  if (t.var.get(nd) == NODE_LEAF) return na == 0 ? 0.0 : S4B_UNI(m.log1mPg[depth]);
+  double r = na == 0 ? -INFINITY : S4B_UNI(m.logPg[depth]);
+  r += -S4B_UNI(m.logInt[na]);
+  int lo, hi; tv_interval(t, m, nd, t.var.get(nd), lo, hi);
+  int width = hi - lo + 1;
+  r += (width >= 1 && width < m.logIntLen) ? -S4B_UNI(m.logInt[width]) : -log((double)width);
+  return r;
+}
+// sum of the own terms over the subtree rooted at `root` (walk order)
+template <class TR> S4B_HD inline double tv_log_prior_subtree(const TR& t, const ModelView& m, int root) {
+  double sum = 0.0;
+  int depth = tv_depth_of(t, root), nd, k; Walker<TR> w(t, root);
+  while (w.next(nd, k)) {
+    if (k == 0) sum += tv_log_prior_own(t, m, nd, depth);
+    else if (k == 1) { sum += tv_log_prior_own(t, m, nd, depth); ++depth; }
+    else --depth;
+  }
+  return sum;
+}
+
+// structure cache of one tree: valid until a move on that tree is accepted
+template <class AI16>
+struct TreeCacheT {
+  AI16 leaf;     // leaves, DFS order
+  AI16 pre;      // internal nodes, pre-order
+  AI16 post;     // internal nodes, post-order
+  int32_t nl, ni;
+  double logPi;  // log tree prior
+  int32_t valid;
+};
+typedef TreeCacheT<PtrArr<int16_t>> TreeCache;
+
+// (re)build memo + lists + log prior of `cur`
+template <class TR, class CA> S4B_HD inline void tv_rebuild_cache(TR& cur, const ModelView& m, CA& c) {
+  tv_fill_info(cur, m, 0);
+  int nl = 0, np = 0, nq = 0, nd, k; Walker<TR> w(cur, 0);
+  while (w.next(nd, k)) {
+    if (k == 0) c.leaf.set(nl++, (int16_t)nd);
+    else if (k == 1) c.pre.set(np++, (int16_t)nd);
+    else c.post.set(nq++, (int16_t)nd);
+  }
+  c.nl = nl; c.ni = np;
+  c.logPi = tv_log_prior(cur, m);
+  c.valid = 1;
+}
+
 template <class TA, class TB> S4B_HD inline void tv_copy(const TA& src, TB& dst, int count) {
   for (int i = 0; i < count; ++i) {
     dst.var.set(i, src.var.get(i)); dst.cut.set(i, src.cut.get(i)); dst.left.set(i, src.left.get(i));
@@ -310,30 +359,31 @@ template <class TR> S4B_HD inline bool tv_rules_valid(const TR& t, const ModelVi
 }
 
 // ------------------------------------------------------------------ propose
-// Fills `pr` and the tables for the next update of tree `cur` (hwm = slots in use).  Preconditions: the node
-// memo of `cur` is filled (tv_fill_info), the proposed tree is a copy of `cur` (memo included) for node
-// ids < hwm, and binA/binB = -1, insub = 0 there.
+// Fills `pr` and the tables for the next update of tree `cur` (hwm = slots in use).  Preconditions: the
+// structure cache `ca` of `cur` is valid (tv_rebuild_cache), the proposed tree is a copy of `cur` (memo
+// included) for node ids < hwm, and binA/binB = -1, insub = 0 there.
 // Returns 0, or -1 when the node capacity is exhausted (the caller raises an error).
-template <class TR, class TBL>
-S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* rng, Proposal* pr, TBL& tb) {
+template <class TR, class TBL, class CA>
+S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* rng, Proposal* pr, TBL& tb, const CA& ca) {
   TR& pt = tb.prop;
-  int nl = tv_list_leaves(cur, 0, tb.list);
-  for (int i = 0; i < nl; ++i) tb.binA.set(tb.list.get(i), (int16_t)i);
+  const int nl = ca.nl, ni = ca.ni;
+  for (int i = 0; i < nl; ++i) tb.binA.set(ca.leaf.get(i), (int16_t)i);
   pr->nbA = nl; pr->nbB = 0; pr->hwm = hwm; pr->node = 0; pr->var = -1; pr->split = -1; pr->status = -1;
   pr->newLeft = pr->newRight = -1; pr->priorRatio = pr->transRatio = 1.0; pr->XLogPi = pr->YLogPi = 0.0;
 
   double u = r_unif(rng);
   if (u < m.pBD) {
-    const bool single = tv_is_leaf(cur, 0);
-    int g = single ? 1 : tv_list_growable(cur, m, tb.list);
-    double pBirthStep = tv_prob_birth_step(cur, m, g);
+    const bool single = ni == 0;
+    int g = 0;   // leaves that can still grow
+    if (single) g = 1; else for (int i = 0; i < nl; ++i) if (tv_num_avail(cur, m, ca.leaf.get(i)) > 0) ++g;
+    double pBirthStep = single ? 1.0 : (g > 0 ? m.pBirth : 0.0);
     if (r_unif(rng) < pBirthStep) {
       pr->type = MOVE_BIRTH;
-      int nd; double pSelect;
-      if (single) { nd = 0; pSelect = 1.0; }
-      else {
+      int nd = 0; double pSelect = 1.0;
+      if (!single) {
         if (g == 0) return 0;
-        nd = tb.list.get(r_unif_int(rng, 0, g));
+        int idx = r_unif_int(rng, 0, g);
+        for (int i = 0; i < nl; ++i) { int lf = ca.leaf.get(i); if (tv_num_avail(cur, m, lf) > 0) { if (idx == 0) { nd = lf; break; } --idx; } }
         pSelect = 1.0 / (double)g;
       }
       int depthNd = tv_depth_of(cur, nd);
@@ -358,7 +408,9 @@ S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* r
       // growable leaves of the proposed tree: the old ones minus nd plus the children that can grow
       int gNew = (single ? 0 : g - 1) + (naL > 0 ? 1 : 0) + (naR > 0 ? 1 : 0);
       double pDeath = 1.0 - (gNew > 0 ? m.pBirth : 0.0);
-      int nog = tv_count_nog(pt);
+      // nodes whose children are both leaves, after the birth: the old ones, minus nd's parent if it was one, plus nd
+      int nog = 1;
+      for (int i = 0; i < ni; ++i) { int q = ca.pre.get(i); if (tv_is_nog(cur, q) && q != cur.parent.get(nd)) ++nog; }
       double pSelectDeath = 1.0 / (double)nog;
       pr->priorRatio = newPrior / oldPrior;
       pr->transRatio = (pDeath * pSelectDeath) / (pBirthStep * pSelect);
@@ -367,9 +419,12 @@ S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* r
       pr->status = 1;
     } else {
       pr->type = MOVE_DEATH;
-      int gn = tv_list_nog(cur, tb.list);
+      int gn = 0;
+      for (int i = 0; i < ni; ++i) if (tv_is_nog(cur, ca.pre.get(i))) ++gn;
       if (gn == 0) return 0;
-      int nd = tb.list.get(r_unif_int(rng, 0, gn));
+      int idx = r_unif_int(rng, 0, gn);
+      int nd = 0;
+      for (int i = 0; i < ni; ++i) { int q = ca.pre.get(i); if (tv_is_nog(cur, q)) { if (idx == 0) { nd = q; break; } --idx; } }
       double pSelect = 1.0 / (double)gn;
       int L = cur.left.get(nd), R = cur.right.get(nd);
       int depthNd = tv_depth_of(cur, nd);
@@ -381,7 +436,7 @@ S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* r
       pt.var.set(nd, NODE_LEAF); pt.left.set(nd, -1); pt.right.set(nd, -1); pt.cut.set(nd, 0);
       pt.var.set(L, NODE_FREE); pt.var.set(R, NODE_FREE);
       double newPrior = 1.0 - pgParent;
-      const bool singleNew = tv_is_leaf(pt, 0);
+      const bool singleNew = nd == 0;
       // growable leaves after the collapse: remove the two children, add the parent
       int numGood = singleNew ? 1 : g - (naL > 0 ? 1 : 0) - (naR > 0 ? 1 : 0) + (naP > 0 ? 1 : 0);
       double pBirthNew = singleNew ? 1.0 : (numGood > 0 ? m.pBirth : 0.0);
@@ -391,11 +446,17 @@ S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* r
       pr->transRatio = (pBirthNew * pSelectBirth) / (pDeath * pSelect);
       pr->node = nd; pr->status = 1;
     }
-  } else if (u < m.pBD + m.pSwap) {
+    return 0;
+  }
+  int nd;
+  if (u < m.pBD + m.pSwap) {
     pr->type = MOVE_SWAP;
-    int g = tv_list_swappable(cur, tb.list);
+    int g = 0;   // internal nodes with at least one internal child, post-order
+    for (int i = 0; i < ni; ++i) if (!tv_is_nog(cur, ca.post.get(i))) ++g;
     if (g == 0) return 0;
-    int nd = tb.list.get(r_unif_int(rng, 0, g));
+    int idx = r_unif_int(rng, 0, g);
+    nd = 0;
+    for (int i = 0; i < ni; ++i) { int q = ca.post.get(i); if (!tv_is_nog(cur, q)) { if (idx == 0) { nd = q; break; } --idx; } }
     int L = cur.left.get(nd), R = cur.right.get(nd);
     int vL = cur.var.get(L), vR = cur.var.get(R);
     bool both = vL >= 0 && vR >= 0 && vL == vR && cur.cut.get(L) == cur.cut.get(R);
@@ -412,17 +473,10 @@ S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* r
     if (both) { pt.var.set(L, pv); pt.cut.set(L, ps); pt.var.set(R, pv); pt.cut.set(R, ps); }
     else { pt.var.set(child, pv); pt.cut.set(child, ps); }
     if (!tv_rules_valid(pt, m, nd)) return 0;
-    tv_fill_info(pt, m, nd);
-    pr->XLogPi = tv_log_prior(cur, m);
-    pr->YLogPi = tv_log_prior(pt, m);
-    int nb = tv_list_leaves(pt, nd, tb.list);
-    for (int i = 0; i < nb; ++i) { int lf = tb.list.get(i); tb.binB.set(lf, (int16_t)(nl + i)); tb.insub.set(lf, 1); }
-    pr->nbB = nb; pr->status = 1;
   } else {
     pr->type = MOVE_CHANGE;
-    int g = tv_list_not_bottom(cur, tb.list);
-    if (g == 0) return 0;
-    int nd = tb.list.get(r_unif_int(rng, 0, g));
+    if (ni == 0) return 0;
+    nd = ca.post.get(r_unif_int(rng, 0, ni));
     pr->node = nd;
     int v = tv_draw_var(cur, m, nd, rng);
     pr->var = v;
@@ -436,13 +490,14 @@ S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* r
     int s = r_unif_int(rng, lo, hi + 1);
     pr->split = s;
     pt.var.set(nd, (int16_t)v); pt.cut.set(nd, (uint16_t)s);
-    tv_fill_info(pt, m, nd);
-    pr->XLogPi = tv_log_prior(cur, m);
-    pr->YLogPi = tv_log_prior(pt, m);
-    int nb = tv_list_leaves(pt, nd, tb.list);
-    for (int i = 0; i < nb; ++i) { int lf = tb.list.get(i); tb.binB.set(lf, (int16_t)(nl + i)); tb.insub.set(lf, 1); }
-    pr->nbB = nb; pr->status = 1;
   }
+  // swap / change: only the subtree under nd changes its prior terms; its leaves keep their DFS order
+  tv_fill_info(pt, m, nd);
+  pr->XLogPi = ca.logPi;
+  pr->YLogPi = (ca.logPi - tv_log_prior_subtree(cur, m, nd)) + tv_log_prior_subtree(pt, m, nd);
+  int nb = tv_list_leaves(pt, nd, tb.list);
+  for (int i = 0; i < nb; ++i) { int lf = tb.list.get(i); tb.binB.set(lf, (int16_t)(nl + i)); tb.insub.set(lf, 1); }
+  pr->nbB = nb; pr->status = 1;
   return 0;
 }
 
@@ -490,10 +545,10 @@ S4B_HD inline void leaves_draw(const AF64& lc, const AF64& ls, const AF64& u1, c
 template <class AF64>
 struct DecideWork { AF64 ll, lc, ls, u1, u2, val; };
 
-template <class TR, class TBL, class AF64, class AI32, class ABIN>
+template <class TR, class TBL, class AF64, class AI32, class ABIN, class CA>
 S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, const ModelView& m, double sigma, MTState* rng,
                          const Proposal* pr, TBL& tb, const ABIN& binCnt, const ABIN& binSum, DecideWork<AF64>& wk,
-                         int32_t* accepted, StepRecord* rec) {
+                         int32_t* accepted, StepRecord* rec, int32_t* cacheValid, const CA& ca) {
   TR& pt = tb.prop;
   sigma = S4B_UNI(sigma);
   const double sigma2 = sigma * sigma;
@@ -539,10 +594,11 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
     cDeath = binCnt.get(bl) + binCnt.get(br); sDeath = binSum.get(bl) + binSum.get(br);
     tb.insub.set(L, 1); tb.insub.set(R, 1);
   }
-  if (acc) { tv_copy(pt, cur, prHwm); hwm = prHwm; }
-  const int nl = tv_list_leaves(cur, 0, tb.list);
+  if (acc) { tv_copy(pt, cur, prHwm); hwm = prHwm; *cacheValid = 0; }
+  // DFS leaf list of the final tree: unchanged (cached) unless the move was accepted
+  const int nl = acc ? tv_list_leaves(cur, 0, tb.list) : ca.nl;
   for (int i = 0; i < nl; ++i) {
-    int n = tb.list.get(i);
+    int n = acc ? tb.list.get(i) : ca.leaf.get(i);
     double lc, ls;
     if (deathAcc && n == nd) { lc = cDeath; ls = sDeath; }
     else {
@@ -554,7 +610,7 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
     if (lc != 0.0) { wk.u1.set(i, r_unif(rng)); wk.u2.set(i, r_unif(rng)); }
   }
   leaves_draw(wk.lc, wk.ls, wk.u1, wk.u2, nl, sigma2, m.leafPrec, wk.val);
-  for (int i = 0; i < nl; ++i) { int n = tb.list.get(i); cnt.set(n, (int32_t)wk.lc.get(i)); mu.set(n, wk.val.get(i)); }
+  for (int i = 0; i < nl; ++i) { int n = acc ? tb.list.get(i) : ca.leaf.get(i); cnt.set(n, (int32_t)wk.lc.get(i)); mu.set(n, wk.val.get(i)); }
   if (rec) { rec->type = prType; rec->status = prStatus == 1 ? acc : -1; rec->var = pr->var; rec->split = pr->split; rec->numLeaves = nl; }
   *accepted = acc;
   return hwm;

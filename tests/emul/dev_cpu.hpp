@@ -32,11 +32,13 @@ class DevCpu {
     var_.assign(m, NODE_FREE); left_.assign(m, -1); right_.assign(m, -1); parent_.assign(m, -1); cut_.assign(m, 0); mu_.assign(m, 0.0); cnt_.assign(m, 0);
     hwm_.assign((size_t)T_, 1);
     for (int t = 0; t < T_; ++t) var_[(size_t)t * nc_] = NODE_LEAF;
+    cna_.assign(m, 0); cdep_.assign(m, 0); cleaf_.assign(m, 0); cpre_.assign(m, 0); cpost_.assign(m, 0);
+    cnl_.assign((size_t)T_, 0); cni_.assign((size_t)T_, 0); cvalid_.assign((size_t)T_, 0); clogpi_.assign((size_t)T_, 0.0);
     for (int s = 0; s < 2; ++s) {
       sc_[s].pvar.assign((size_t)nc_, 0); sc_[s].pleft.assign((size_t)nc_, 0); sc_[s].pright.assign((size_t)nc_, 0); sc_[s].pparent.assign((size_t)nc_, 0);
       sc_[s].pcut.assign((size_t)nc_, 0); sc_[s].binA.assign((size_t)nc_, 0); sc_[s].binB.assign((size_t)nc_, 0); sc_[s].list.assign((size_t)nc_, 0);
       sc_[s].insub.assign((size_t)nc_, 0); sc_[s].muOld.assign((size_t)nc_, 0.0);
-      sc_[s].cna.assign((size_t)nc_, 0); sc_[s].cdep.assign((size_t)nc_, 0); sc_[s].pna.assign((size_t)nc_, 0); sc_[s].pdep.assign((size_t)nc_, 0);
+      sc_[s].pna.assign((size_t)nc_, 0); sc_[s].pdep.assign((size_t)nc_, 0);
       sc_[s].work.assign((size_t)12 * nc_, 0.0);
     }
     binCnt_.assign((size_t)2 * nc_, 0.0); binSum_.assign((size_t)2 * nc_, 0.0);
@@ -49,12 +51,14 @@ class DevCpu {
     a_.userOffset = user_.empty() ? nullptr : user_.data(); a_.leaf = leaf_.data();
     a_.var = var_.data(); a_.left = left_.data(); a_.right = right_.data(); a_.parent = parent_.data(); a_.cut = cut_.data(); a_.mu = mu_.data();
     a_.cnt = cnt_.data(); a_.hwm = hwm_.data();
+    a_.cna = cna_.data(); a_.cdep = cdep_.data(); a_.cleaf = cleaf_.data(); a_.cpre = cpre_.data(); a_.cpost = cpost_.data();
+    a_.cnl = cnl_.data(); a_.cni = cni_.data(); a_.cvalid = cvalid_.data(); a_.clogpi = clogpi_.data();
     for (int s = 0; s < 2; ++s) {
       StepScratch& c = a_.sc[s];
       c.pvar = sc_[s].pvar.data(); c.pleft = sc_[s].pleft.data(); c.pright = sc_[s].pright.data(); c.pparent = sc_[s].pparent.data(); c.pcut = sc_[s].pcut.data();
       c.binA = sc_[s].binA.data(); c.binB = sc_[s].binB.data(); c.list = sc_[s].list.data(); c.insub = sc_[s].insub.data(); c.muOld = sc_[s].muOld.data();
       c.prop = &sc_[s].prop; c.accepted = &sc_[s].accepted;
-      c.cna = sc_[s].cna.data(); c.cdep = sc_[s].cdep.data(); c.pna = sc_[s].pna.data(); c.pdep = sc_[s].pdep.data(); c.work = sc_[s].work.data();
+      c.pna = sc_[s].pna.data(); c.pdep = sc_[s].pdep.data(); c.work = sc_[s].work.data();
     }
     a_.partCnt = nullptr; a_.partSum = nullptr; a_.binCnt = binCnt_.data(); a_.binSum = binSum_.data();
     a_.rng = &rng_; a_.scale = &scale_; a_.numCuts = numCuts_.data();
@@ -73,6 +77,7 @@ class DevCpu {
     size_t m = (size_t)T_ * nc_;
     std::memcpy(var_.data(), var, m * 2); std::memcpy(cut_.data(), cut, m * 2); std::memcpy(left_.data(), left, m * 2); std::memcpy(right_.data(), right, m * 2);
     std::memcpy(parent_.data(), parent, m * 2); std::memcpy(mu_.data(), mu, m * 8); std::memcpy(hwm_.data(), hwm, (size_t)T_ * 4);
+    std::fill(cvalid_.begin(), cvalid_.end(), 0);
   }
   void download_trees(int16_t* var, uint16_t* cut, int16_t* left, int16_t* right, int16_t* parent, double* mu, int32_t* cnt, int32_t* hwm) {
     size_t m = (size_t)T_ * nc_;
@@ -245,14 +250,15 @@ class DevCpu {
     }
   }
 
-  struct Scratch { std::vector<int16_t> pvar, pleft, pright, pparent, binA, binB, list, cna, cdep, pna, pdep; std::vector<double> work; std::vector<uint16_t> pcut; std::vector<uint8_t> insub;
+  struct Scratch { std::vector<int16_t> pvar, pleft, pright, pparent, binA, binB, list, pna, pdep; std::vector<double> work; std::vector<uint16_t> pcut; std::vector<uint8_t> insub;
                    std::vector<double> muOld; Proposal prop; int32_t accepted = 0; };
   DevInit di_;
   size_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0;
   std::vector<uint16_t> xbin_, xbinTest_, leaf_, cut_;
   std::vector<int32_t> numCuts_, cnt_, hwm_, v_, u_;
   std::vector<double> y_, user_, X_, w_, R_, off_, offNew_, e0_, mu_, binCnt_, binSum_;
-  std::vector<int16_t> var_, left_, right_, parent_;
+  std::vector<int16_t> var_, left_, right_, parent_, cna_, cdep_, cleaf_, cpre_, cpost_;
+  std::vector<int32_t> cnl_, cni_, cvalid_; std::vector<double> clogpi_;
   Scratch sc_[2];
   std::vector<StepRecord> trace_;
   MTState rng_; ScaleState scale_; BartArrays a_;

@@ -80,7 +80,7 @@ def test_large_node_capacity_global_fallback(oracle_lib, hip_lib):
     """node_capacity large enough that the control kernel cannot stage the tree in LDS (global-memory path)."""
     args, _ = friedman_case(n=300, T=5, warmup=5, iter=10)
     a = run_chain(oracle_lib, "orc_", args)
-    args.node_capacity = 4000
+    args.node_capacity = 3000
     b = run_chain(hip_lib, "s4b_", args)
     assert_chain_parity(a, b)
 
