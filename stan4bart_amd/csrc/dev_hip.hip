@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -33,7 +34,7 @@ namespace s4b {
   } while (0)
 
 constexpr int BLOCK = 256;          // 4 waves
-constexpr int GRID_MAX = 512;       // workgroups of the O(N) kernels (2 per CU); also the number of partials per bin
+constexpr int GRID_MAX = 2048;      // upper bound on workgroups of the O(N) kernels (8 per CU); also the number of partials per bin
 constexpr int NBMAX = 16;           // bins accumulated in registers per pass
 
 // ------------------------------------------------------------------------------------------------
@@ -55,111 +56,121 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_stats: one pass over (R, leaf_t, [xbin columns of the proposal]) -> per-workgroup (count, sum) of the
-// partial residual r_i = R_i + mu_t[leaf_t(i)] for the A bins (current leaves) and the B bins (leaves the
-// pending proposal would create under its root).
-struct StatsTables {   // LDS image, entries valid for node ids < hwm
-  double* mu; int16_t* binA; int16_t* binB; int16_t* pvar; uint16_t* pcut; int16_t* pleft; int16_t* pright; uint8_t* insub;
+// k_tree: the O(N) kernel of one tree update.  One pass over the observations:
+//   apply half  (tree t-1, already decided):  R_i += mu_old[leaf] - mu_new[leaf'], relabel under the accepted move
+//   stats half  (tree t, proposal pending):   (count, sum) of r_i = R_i + mu_t[leaf_t(i)] per A bin (current leaf)
+//                                             and per B bin (leaf the proposal would create under its root)
+// so the residual is read once and written once per tree update (22 B of algorithmic traffic per
+// observation: R 8+8, leaf(t-1) 2, leaf(t) 2, binned predictor 2).
+// Per-node tables live in LDS as packed 16-byte records (one ds_read_b128 per observation and half).
+struct __attribute__((aligned(16))) NodeS { double mu; int16_t binA, binB; int16_t insub; int16_t pad; };   // stats half
+struct __attribute__((aligned(16))) NodeP { int16_t var; uint16_t cut; int16_t left, right; };               // 8 B: routing
+struct __attribute__((aligned(16))) NodeA { double muOld, muNew; };                                           // apply half
+
+typedef unsigned short us4_t __attribute__((ext_vector_type(4)));
+static size_t apply_lds_bytes(int nc) { return (size_t)nc * 25 + 16; }
+
+struct TreeLds {
+  NodeS* S; NodeP* SP;     // stats: records + proposed-tree routing
+  NodeA* A; NodeP* AP; uint8_t* Ain;   // apply: records + new-tree routing + re-route flags
+  double* redS; int* redN;
 };
-
-__device__ __forceinline__ StatsTables carve_stats(unsigned char* base, int nc) {
-  StatsTables s;
-  s.mu = (double*)base; base += (size_t)nc * 8;
-  s.binA = (int16_t*)base; base += (size_t)nc * 2;
-  s.binB = (int16_t*)base; base += (size_t)nc * 2;
-  s.pvar = (int16_t*)base; base += (size_t)nc * 2;
-  s.pcut = (uint16_t*)base; base += (size_t)nc * 2;
-  s.pleft = (int16_t*)base; base += (size_t)nc * 2;
-  s.pright = (int16_t*)base; base += (size_t)nc * 2;
-  s.insub = (uint8_t*)base;
-  return s;
+__host__ __device__ static inline size_t tree_lds_bytes(int nc) {
+  return (size_t)nc * (16 + 8 + 16 + 8) + ((size_t)nc + 15) / 16 * 16 + 4 * 16 * 8 + 4 * 16 * 4;
 }
-__host__ __device__ static inline size_t stats_lds_bytes(int nc) { return ((size_t)nc * (8 + 6 * 2 + 1) + 15) / 16 * 16 + 2 * 4 * NBMAX * 8; }
-
-// tables of the apply half (tree t-1): leaf values before / after its update, its (new) structure and the
-// leaves whose observations must be re-routed
-struct ApplyTables { double* muOld; double* muNew; int16_t* var; uint16_t* cut; int16_t* left; int16_t* right; uint8_t* insub; };
-__device__ __forceinline__ ApplyTables carve_apply(unsigned char* base, int nc) {
-  ApplyTables p;
-  p.muOld = (double*)base; base += (size_t)nc * 8;
-  p.muNew = (double*)base; base += (size_t)nc * 8;
-  p.var = (int16_t*)base; base += (size_t)nc * 2;
-  p.cut = (uint16_t*)base; base += (size_t)nc * 2;
-  p.left = (int16_t*)base; base += (size_t)nc * 2;
-  p.right = (int16_t*)base; base += (size_t)nc * 2;
-  p.insub = (uint8_t*)base;
-  return p;
+__device__ __forceinline__ TreeLds carve_tree(unsigned char* base, int nc) {
+  TreeLds L;
+  L.S = (NodeS*)base; base += (size_t)nc * 16;
+  L.A = (NodeA*)base; base += (size_t)nc * 16;
+  L.SP = (NodeP*)base; base += (size_t)nc * 8;
+  L.AP = (NodeP*)base; base += (size_t)nc * 8;
+  L.Ain = (uint8_t*)base; base += ((size_t)nc + 15) / 16 * 16;
+  L.redS = (double*)base; base += 4 * 16 * 8;
+  L.redN = (int*)base;
+  return L;
 }
-static size_t apply_lds_bytes(int nc) { return ((size_t)nc * 25 + 15) / 16 * 16; }
-static size_t tree_lds_bytes(int nc) { return stats_lds_bytes(nc) + apply_lds_bytes(nc); }
 
-// One pass over the observations for tree t.  APPLY: first finish tree t-1 (R_i += mu_old - mu_new, relabel
-// the observations under its accepted move) — the residual is then read once and written once per tree
-// update.  Then accumulate the (count, sum) bins [base, base + NB) of tree t's pending proposal.
 template <int NB, bool APPLY>
-__device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const StatsTables& L, const ApplyTables& Q, int root, int prevRoot,
-                                          int prevAcc, int base, int nbTotal, double* redS, double* redN) {
-  double accS[NB], accN[NB];
+__device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const TreeLds& L, int root, int prevRoot, int prevAcc, int base,
+                                          int nbTotal) {
+  double accS[NB]; int accN[NB];
 #pragma unroll
-  for (int k = 0; k < NB; ++k) { accS[k] = 0.0; accN[k] = 0.0; }
+  for (int k = 0; k < NB; ++k) { accS[k] = 0.0; accN[k] = 0; }
   const int64_t nQuads = (a.n + 3) >> 2;
   const uint16_t* __restrict__ leafPlane = a.leaf + (size_t)t * a.npad;
   uint16_t* __restrict__ prevPlane = a.leaf + (size_t)(t > 0 ? t - 1 : 0) * a.npad;
   double* __restrict__ R = a.R;
-  for (int64_t qd = (int64_t)blockIdx.x * BLOCK + threadIdx.x; qd < nQuads; qd += (int64_t)gridDim.x * BLOCK) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  int64_t qd = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  // software prefetch: the loads of the next quad are issued before the current one is processed
+  double2 r01, r23; us4_t lf4, pl4;
+  if (qd < nQuads) {
     const int64_t i0 = qd << 2;
-    const double2 r01 = *reinterpret_cast<const double2*>(R + i0);
-    const double2 r23 = *reinterpret_cast<const double2*>(R + i0 + 2);
-    const ushort4 lf4 = *reinterpret_cast<const ushort4*>(leafPlane + i0);
+    r01 = *reinterpret_cast<const double2*>(R + i0); r23 = *reinterpret_cast<const double2*>(R + i0 + 2);
+    lf4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(leafPlane + i0));
+    if (APPLY) pl4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(prevPlane + i0));
+  }
+  for (; qd < nQuads; qd += stride) {
+    const int64_t i0 = qd << 2;
     double rr[4] = {r01.x, r01.y, r23.x, r23.y};
     const unsigned lf[4] = {lf4.x, lf4.y, lf4.z, lf4.w};
+    unsigned pl[4] = {pl4.x, pl4.y, pl4.z, pl4.w};
+    const int64_t qn = qd + stride;
+    if (qn < nQuads) {
+      const int64_t j0 = qn << 2;
+      r01 = *reinterpret_cast<const double2*>(R + j0); r23 = *reinterpret_cast<const double2*>(R + j0 + 2);
+      lf4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(leafPlane + j0));
+      if (APPLY) pl4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(prevPlane + j0));
+    }
+    const int valid = (a.n - i0) >= 4 ? 4 : (int)(a.n - i0);
     if (APPLY) {
-      const ushort4 pl4 = *reinterpret_cast<const ushort4*>(prevPlane + i0);
-      unsigned pl[4] = {pl4.x, pl4.y, pl4.z, pl4.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (i0 + e >= a.n) break;
-        const unsigned l = pl[e];
+        const unsigned l = e < valid ? pl[e] : 0u;
+        const NodeA na = L.A[l];
         unsigned nl = l;
-        if (prevAcc && Q.insub[l]) {
+        double muNew = na.muNew;
+        if (prevAcc && e < valid && L.Ain[l]) {
           int nd = prevRoot;
-          int v = Q.var[nd];
-          while (v >= 0) {
-            const unsigned x = a.xbin[(size_t)v * a.npad + (size_t)(i0 + e)];
-            nd = (x <= (unsigned)Q.cut[nd]) ? Q.left[nd] : Q.right[nd];
-            v = Q.var[nd];
+          NodeP p = L.AP[nd];
+          while (p.var >= 0) {
+            const unsigned x = a.xbin[(size_t)p.var * a.npad + (size_t)(i0 + e)];
+            nd = (x <= (unsigned)p.cut) ? p.left : p.right;
+            p = L.AP[nd];
           }
           nl = (unsigned)nd;
+          muNew = L.A[nl].muNew;
         }
-        rr[e] = (rr[e] + Q.muOld[l]) - Q.muNew[nl];
+        rr[e] = (rr[e] + na.muOld) - muNew;
         pl[e] = nl;
       }
       *reinterpret_cast<double2*>(R + i0) = make_double2(rr[0], rr[1]);
       *reinterpret_cast<double2*>(R + i0 + 2) = make_double2(rr[2], rr[3]);
-      if (prevAcc) *reinterpret_cast<ushort4*>(prevPlane + i0) = make_ushort4((unsigned short)pl[0], (unsigned short)pl[1], (unsigned short)pl[2], (unsigned short)pl[3]);
+      if (prevAcc) { us4_t o4; o4.x = (unsigned short)pl[0]; o4.y = (unsigned short)pl[1]; o4.z = (unsigned short)pl[2]; o4.w = (unsigned short)pl[3];
+                     __builtin_nontemporal_store(o4, reinterpret_cast<us4_t*>(prevPlane + i0)); }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (i0 + e >= a.n) break;
-      const unsigned l = lf[e];
-      const double r = rr[e] + L.mu[l];
-      const int ba = (int)L.binA[l] - base;
+      const bool ok = e < valid;
+      const NodeS ns = L.S[ok ? lf[e] : 0u];
+      const double r = rr[e] + ns.mu;
+      const int ba = ok ? (int)ns.binA - base : -1;
       int bb = -1 - base;
-      if (L.insub[l]) {
+      if (ok && ns.insub) {
         int nd = root;
-        int v = L.pvar[nd];
-        while (v >= 0) {
-          const unsigned x = a.xbin[(size_t)v * a.npad + (size_t)(i0 + e)];
-          nd = (x <= (unsigned)L.pcut[nd]) ? L.pleft[nd] : L.pright[nd];
-          v = L.pvar[nd];
+        NodeP p = L.SP[nd];
+        while (p.var >= 0) {
+          const unsigned x = a.xbin[(size_t)p.var * a.npad + (size_t)(i0 + e)];
+          nd = (x <= (unsigned)p.cut) ? p.left : p.right;
+          p = L.SP[nd];
         }
-        bb = (int)L.binB[nd] - base;
+        bb = (int)L.S[nd].binB - base;
       }
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         const bool m = (ba == k) | (bb == k);
         accS[k] += m ? r : 0.0;
-        accN[k] += m ? 1.0 : 0.0;
+        accN[k] += m ? 1 : 0;
       }
     }
   }
@@ -167,34 +178,35 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Stat
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
-    const double s = wave_sum(accS[k]), c = wave_sum(accN[k]);
-    if (lane == 0) { redS[wv * NBMAX + k] = s; redN[wv * NBMAX + k] = c; }
+    const double s = wave_sum(accS[k]);
+    int c = accN[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) { L.redS[wv * NBMAX + k] = s; L.redN[wv * NBMAX + k] = c; }
   }
   __syncthreads();
   if ((int)threadIdx.x < NB && base + (int)threadIdx.x < nbTotal) {
     const int k = threadIdx.x;
-    const double s = ((redS[k] + redS[NBMAX + k]) + redS[2 * NBMAX + k]) + redS[3 * NBMAX + k];
-    const double c = ((redN[k] + redN[NBMAX + k]) + redN[2 * NBMAX + k]) + redN[3 * NBMAX + k];
+    const double s = ((L.redS[k] + L.redS[NBMAX + k]) + L.redS[2 * NBMAX + k]) + L.redS[3 * NBMAX + k];
+    const int c = L.redN[k] + L.redN[NBMAX + k] + L.redN[2 * NBMAX + k] + L.redN[3 * NBMAX + k];
     a.partSum[(size_t)(base + k) * a.grid + blockIdx.x] = s;
-    a.partCnt[(size_t)(base + k) * a.grid + blockIdx.x] = c;
+    a.partCnt[(size_t)(base + k) * a.grid + blockIdx.x] = (double)c;
   }
   __syncthreads();
 }
 
-// k_tree<APPLY>: the O(N) kernel of one tree update.  APPLY = false for the first tree of a sweep.
+// APPLY = false for the first tree of a sweep (nothing pending)
 template <bool APPLY>
 __global__ __launch_bounds__(BLOCK) void k_tree(BartArrays a, int t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const StepScratch& c = a.sc[t & 1];
   const Proposal pr = *c.prop;
-  StatsTables L = carve_stats(smem, a.nc);
-  double* redS = (double*)(smem + ((size_t)a.nc * 21 + 15) / 16 * 16);
-  double* redN = redS + 4 * NBMAX;
-  ApplyTables Q = carve_apply(smem + stats_lds_bytes(a.nc), a.nc);
+  const TreeLds L = carve_tree(smem, a.nc);
   const double* mu = a.mu + (size_t)t * a.nc;
   for (int i = threadIdx.x; i < pr.hwm; i += BLOCK) {
-    L.mu[i] = mu[i]; L.binA[i] = c.binA[i]; L.binB[i] = c.binB[i]; L.pvar[i] = c.pvar[i]; L.pcut[i] = c.pcut[i];
-    L.pleft[i] = c.pleft[i]; L.pright[i] = c.pright[i]; L.insub[i] = c.insub[i];
+    NodeS s; s.mu = mu[i]; s.binA = c.binA[i]; s.binB = c.binB[i]; s.insub = c.insub[i]; s.pad = 0;
+    NodeP p; p.var = c.pvar[i]; p.cut = c.pcut[i]; p.left = c.pleft[i]; p.right = c.pright[i];
+    L.S[i] = s; L.SP[i] = p;
   }
   int prevAcc = 0, prevRoot = 0;
   if (APPLY) {
@@ -203,18 +215,19 @@ __global__ __launch_bounds__(BLOCK) void k_tree(BartArrays a, int t) {
     const int hp = cp.prop->hwm > a.hwm[t - 1] ? cp.prop->hwm : a.hwm[t - 1];
     const size_t o = (size_t)(t - 1) * a.nc;
     for (int i = threadIdx.x; i < hp; i += BLOCK) {
-      Q.muOld[i] = cp.muOld[i]; Q.muNew[i] = a.mu[o + i]; Q.var[i] = a.var[o + i]; Q.cut[i] = a.cut[o + i]; Q.left[i] = a.left[o + i];
-      Q.right[i] = a.right[o + i]; Q.insub[i] = cp.insub[i];
+      NodeA q; q.muOld = cp.muOld[i]; q.muNew = a.mu[o + i];
+      NodeP p; p.var = a.var[o + i]; p.cut = a.cut[o + i]; p.left = a.left[o + i]; p.right = a.right[o + i];
+      L.A[i] = q; L.AP[i] = p; L.Ain[i] = cp.insub[i];
     }
   }
   __syncthreads();
   const int nb = pr.nbA + pr.nbB;
-  if (nb <= 4) tree_pass<4, APPLY>(a, t, L, Q, pr.node, prevRoot, prevAcc, 0, nb, redS, redN);
-  else if (nb <= 8) tree_pass<8, APPLY>(a, t, L, Q, pr.node, prevRoot, prevAcc, 0, nb, redS, redN);
+  if (nb <= 4) tree_pass<4, APPLY>(a, t, L, pr.node, prevRoot, prevAcc, 0, nb);
+  else if (nb <= 8) tree_pass<8, APPLY>(a, t, L, pr.node, prevRoot, prevAcc, 0, nb);
   else {
-    tree_pass<NBMAX, APPLY>(a, t, L, Q, pr.node, prevRoot, prevAcc, 0, nb, redS, redN);
+    tree_pass<NBMAX, APPLY>(a, t, L, pr.node, prevRoot, prevAcc, 0, nb);
     // further bin passes read the residual this thread has just written
-    for (int base = NBMAX; base < nb; base += NBMAX) tree_pass<NBMAX, false>(a, t, L, Q, pr.node, prevRoot, prevAcc, base, nb, redS, redN);
+    for (int base = NBMAX; base < nb; base += NBMAX) tree_pass<NBMAX, false>(a, t, L, pr.node, prevRoot, prevAcc, base, nb);
   }
 }
 
@@ -733,7 +746,13 @@ class DevHip {
     a = BartArrays{};
     a.n = n_; a.npad = (n_ + 7) / 8 * 8; a.P = P_; a.T = T_; a.nc = nc_; a.nTest = nTest_; a.nTestPad = (nTest_ + 7) / 8 * 8;
     const int64_t nQuads = (n_ + 3) / 4;
-    a.grid = (int)std::min<int64_t>(GRID_MAX, std::max<int64_t>(1, (nQuads + BLOCK - 1) / BLOCK));
+    // fixed launch geometry (=> fixed reduction order): ~8 quads per thread, between 1 and GRID_MAX workgroups;
+    // S4B_GRID overrides it (tuning experiments)
+    // measured on MI355X (profiles/r01_grid_sweep.txt): <= 512 workgroups with ~2 quads per thread while the kernel is
+    // latency-bound (n ~ 1e6), 1024 workgroups once there are >= 8 quads per thread (n ~ 1e7: 43 % of HBM peak)
+    a.grid = (int)std::max<int64_t>(1, (nQuads + (int64_t)BLOCK * 2 - 1) / ((int64_t)BLOCK * 2));
+    if (a.grid > 512) a.grid = (int)std::min<int64_t>(1024, std::max<int64_t>(512, (nQuads + (int64_t)BLOCK * 8 - 1) / ((int64_t)BLOCK * 8)));
+    if (const char* g = getenv("S4B_GRID")) { int v = atoi(g); if (v >= 1 && v <= GRID_MAX) a.grid = v; }
     a.binCap = 2 * nc_; a.traceCap = d.traceCap;
     // ---- observation-length arrays
     uint16_t* xb = alloc<uint16_t>((size_t)P_ * a.npad);
@@ -808,7 +827,7 @@ class DevHip {
     if (nTest_) testOut_ = zalloc<double>((size_t)nTest_);
     // ---- launch configuration
     gridN_ = a.grid;   // one launch geometry for every O(N) kernel: the partial buffers are sized by it
-    ldsStats_ = stats_lds_bytes(nc_); ldsApply_ = apply_lds_bytes(nc_); ldsTree_ = tree_lds_bytes(nc_); ldsControl_ = control_lds_bytes(P_, d.model.logIntLen);
+    ldsApply_ = apply_lds_bytes(nc_); ldsTree_ = tree_lds_bytes(nc_); ldsControl_ = control_lds_bytes(P_, d.model.logIntLen);
     if (ldsTree_ > 64 * 1024) {
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
@@ -1019,7 +1038,7 @@ class DevHip {
 
   int device_ = 0; hipStream_t stream_ = nullptr; hipEvent_t evStart_ = nullptr, evStop_ = nullptr;
   int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1;
-  size_t ldsStats_ = 0, ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0;
+  size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0;
   BartArrays a_; StanArrays s_;
   std::vector<void*> allocs_;
   double* pinned_ = nullptr; double* testOut_ = nullptr;
