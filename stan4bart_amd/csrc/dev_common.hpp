@@ -41,6 +41,8 @@ struct BartArrays {
   double* off;                 // [n]  current BART offset (parametric mean [+ user offset])
   double* offNew;              // [n]  next offset
   const double* userOffset;    // [n] or null
+  double* lat;                 // [n] probit only: latent response with the offset removed (dbarts probitLatents)
+  int32_t binary;
   uint16_t* leaf;              // [T][npad] node id of the leaf holding observation i in tree t
   // trees, [T][nc]
   int16_t *var, *left, *right, *parent; uint16_t* cut; double* mu; int32_t* cnt; int32_t* hwm;

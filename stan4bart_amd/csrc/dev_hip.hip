@@ -508,7 +508,7 @@ __global__ __launch_bounds__(BLOCK) void k_apply(BartArrays a, int t) {
 __global__ __launch_bounds__(BLOCK) void k_assign_leaves(BartArrays a) {
   const ScaleState sc = *a.scale;
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK) {
-    double r = (a.y[i] - a.off[i] - sc.min) / sc.range - 0.5;
+    double r = a.binary ? a.lat[i] : (a.y[i] - a.off[i] - sc.min) / sc.range - 0.5;
     for (int t = 0; t < a.T; ++t) {
       const size_t o = (size_t)t * a.nc;
       int nd = 0;
@@ -609,6 +609,73 @@ __global__ __launch_bounds__(BLOCK) void k_rescale(BartArrays a, int update) {
   }
 }
 
+// probit: latent response z_i ~ N(fit_i + offset_i, 1) truncated to (0, inf) if y_i = 1, (-inf, 0] otherwise
+// (dbarts sampleProbitLatentVariables; reference consumes it through storeLatents, src/init.cpp:289,845).
+// The draws come from R's sequential generator with a data-dependent number of uniforms per observation, so the
+// stream order forces a serial loop: one workgroup stages chunks through LDS, lane 0 draws, all lanes store.
+__device__ double lower_trunc_std_normal(MTState* rng, double lower) {
+  double x;
+  if (lower < 0.0) { x = r_norm(rng); while (x < lower) x = r_norm(rng); }
+  else {
+    const double aa = 0.5 * (lower + sqrt(lower * lower + 4.0));
+    double u, r;
+    do { x = r_exp(rng) / aa + lower; u = r_unif(rng); const double d = x - aa; r = exp(-0.5 * d * d); } while (u > r);
+  }
+  return x;
+}
+constexpr int LAT_CHUNK = 2048;
+__global__ __launch_bounds__(BLOCK) void k_latents(BartArrays a) {
+  __shared__ MTState s_rng;
+  __shared__ double s_mean[LAT_CHUNK];   // in: fit + offset, out: z
+  __shared__ unsigned char s_pos[LAT_CHUNK];
+  for (int i = threadIdx.x; i < (int)(sizeof(MTState) / 4); i += BLOCK) ((uint32_t*)&s_rng)[i] = ((const uint32_t*)a.rng)[i];
+  for (int64_t c0 = 0; c0 < a.n; c0 += LAT_CHUNK) {
+    const int len = (int)((a.n - c0) < LAT_CHUNK ? (a.n - c0) : LAT_CHUNK);
+    __syncthreads();
+    for (int j = threadIdx.x; j < len; j += BLOCK) {
+      const int64_t i = c0 + j;
+      s_mean[j] = (a.lat[i] - a.R[i]) + a.off[i];
+      s_pos[j] = a.y[i] > 0.0 ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int j = 0; j < len; ++j) {
+        const double mean = s_mean[j];
+        s_mean[j] = s_pos[j] ? mean + lower_trunc_std_normal(&s_rng, 0.0 - mean) : mean - lower_trunc_std_normal(&s_rng, mean - 0.0);
+      }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < len; j += BLOCK) {
+      const int64_t i = c0 + j;
+      const double F = a.lat[i] - a.R[i];
+      const double nl = s_mean[j] - a.off[i];
+      a.lat[i] = nl; a.R[i] = nl - F;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (int)(sizeof(MTState) / 4); i += BLOCK) ((uint32_t*)a.rng)[i] = ((const uint32_t*)&s_rng)[i];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_init_binary(BartArrays a) {   // latents 2y - 1, no tree fits yet
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    ScaleState sc; sc.min = -0.5; sc.max = 0.5; sc.range = 1.0; sc.min0 = -0.5; sc.range0 = 1.0; sc.shiftPerTree = 0.0; sc.sigmaData = 1.0; sc.sigma = 1.0;
+    *a.scale = sc;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK) {
+    const double z = 2.0 * a.y[i] - 1.0;
+    a.lat[i] = z; a.R[i] = z;
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_rescale_binary(BartArrays a) {   // keep latent + offset invariant
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK) {
+    const double old = a.lat[i];
+    const double nl = old + (a.off[i] - a.offNew[i]);
+    a.R[i] += nl - old;
+    a.lat[i] = nl;
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_init_residual(BartArrays a) {   // all tree fits zero: R = yRescaled
   const ScaleState sc = *a.scale;
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK)
@@ -640,13 +707,13 @@ __global__ __launch_bounds__(BLOCK) void k_stan_inputs(BartArrays a, StanArrays 
     double e;
     if (direct) e = s.e0[i] - param_mean_at(s, a.n, i, 1, 1);
     else {
-      double fit = 0.0;
+      double fit = 0.0, resp = a.y[i];
       if (mode != 0 || wantTrain) {
-        const double yr = (a.y[i] - a.off[i] - sc.min) / sc.range - 0.5;
-        fit = ((yr - a.R[i]) + 0.5) * sc.range + sc.min;
+        if (a.binary) { const double z = a.lat[i]; fit = z - a.R[i]; if (mode != 0) resp = z + a.off[i]; }
+        else { const double yr = (a.y[i] - a.off[i] - sc.min) / sc.range - 0.5; fit = ((yr - a.R[i]) + 0.5) * sc.range + sc.min; }
       }
       const double so = mode == 0 ? 0.0 : mode == 1 ? fit : mode == 2 ? a.userOffset[i] : fit + a.userOffset[i];
-      e = a.y[i] - so;
+      e = resp - so;
       if (wantTrain) s.train[i] = fit;
     }
     dstE[i] = e;
@@ -715,7 +782,7 @@ __global__ __launch_bounds__(BLOCK) void k_test_fits(BartArrays a, double* out) 
       }
       f += a.mu[o + nd];
     }
-    out[i] = (f + 0.5) * sc.range + sc.min;
+    out[i] = a.binary ? f : (f + 0.5) * sc.range + sc.min;
   }
 }
 
@@ -769,6 +836,8 @@ class DevHip {
     a.off = alloc<double>((size_t)a.npad); HIP_OK(hipMemsetAsync(a.off, 0, (size_t)a.npad * 8, stream_));
     a.offNew = alloc<double>((size_t)a.npad); HIP_OK(hipMemsetAsync(a.offNew, 0, (size_t)a.npad * 8, stream_));
     if (d.userOffset) { double* uo = alloc<double>((size_t)a.npad); upload(uo, d.userOffset, (size_t)n_); a.userOffset = uo; }
+    a.binary = d.binary; binary_ = d.binary != 0;
+    if (binary_) a.lat = zalloc<double>((size_t)a.npad);
     a.leaf = alloc<uint16_t>((size_t)T_ * a.npad); HIP_OK(hipMemsetAsync(a.leaf, 0, (size_t)T_ * a.npad * 2, stream_));
     // ---- trees
     const size_t m = (size_t)T_ * nc_;
@@ -835,10 +904,13 @@ class DevHip {
     if (ldsApply_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsApply_));
     if (ldsTree_ > 160 * 1024) throw std::runtime_error("node_capacity too large for the 160 KiB LDS of a CU");
     // ---- initial scale from the raw response (offset 0), R = yRescaled
-    hipLaunchKernelGGL(k_param_mean, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, 0, 0, 0, 1, a_.offNew); ++launches_;
-    hipLaunchKernelGGL(k_scale, dim3(1), dim3(BLOCK), 0, stream_, a_, s_, 1, gridN_); ++launches_;
-    HIP_OK(hipMemsetAsync(a_.mu, 0, (size_t)T_ * nc_ * 8, stream_));   // the very first scale has no tree fits to carry over
-    hipLaunchKernelGGL(k_init_residual, dim3(gridN_), dim3(BLOCK), 0, stream_, a_); ++launches_;
+    if (binary_) { hipLaunchKernelGGL(k_init_binary, dim3(gridN_), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+    else {
+      hipLaunchKernelGGL(k_param_mean, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, 0, 0, 0, 1, a_.offNew); ++launches_;
+      hipLaunchKernelGGL(k_scale, dim3(1), dim3(BLOCK), 0, stream_, a_, s_, 1, gridN_); ++launches_;
+      HIP_OK(hipMemsetAsync(a_.mu, 0, (size_t)T_ * nc_ * 8, stream_));   // the very first scale has no tree fits to carry over
+      hipLaunchKernelGGL(k_init_residual, dim3(gridN_), dim3(BLOCK), 0, stream_, a_); ++launches_;
+    }
     sync();
   }
 
@@ -888,6 +960,11 @@ class DevHip {
   }
   void set_sigma(double s) { hipLaunchKernelGGL(k_set_sigma, dim3(1), dim3(1), 0, stream_, a_, s); ++launches_; }
   void rescale(bool update) {
+    if (binary_) {
+      hipLaunchKernelGGL(k_rescale_binary, dim3(gridN_), dim3(BLOCK), 0, stream_, a_); ++launches_;
+      std::swap(a_.off, a_.offNew);
+      return;
+    }
     hipLaunchKernelGGL(k_scale, dim3(1), dim3(BLOCK), 0, stream_, a_, s_, update ? 1 : 0, gridN_); ++launches_;
     hipLaunchKernelGGL(k_rescale, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, update ? 1 : 0); ++launches_;
     std::swap(a_.off, a_.offNew);
@@ -906,6 +983,7 @@ class DevHip {
         launches_ += 2;
       }
       hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, T_ - 1); ++launches_;
+      if (binary_) { hipLaunchKernelGGL(k_latents, dim3(1), dim3(BLOCK), 0, stream_, a_); ++launches_; }
     }
   }
   // per-launch HIP-event timing of extra sweeps on the sampler's stream (bench.py roofline leg)
@@ -1037,7 +1115,7 @@ class DevHip {
   }
 
   int device_ = 0; hipStream_t stream_ = nullptr; hipEvent_t evStart_ = nullptr, evStop_ = nullptr;
-  int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1;
+  int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1; bool binary_ = false;
   size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0;
   BartArrays a_; StanArrays s_;
   std::vector<void*> allocs_;

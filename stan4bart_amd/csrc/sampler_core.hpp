@@ -36,7 +36,7 @@ struct DevInit {
   const double* y = nullptr;
   const double* userOffset = nullptr;
   ModelView model;
-  int32_t K = 0, q = 0;
+  int32_t K = 0, q = 0, binary = 0;
   const double* X = nullptr;           // n x K column-major
   const double* w = nullptr; const int32_t* v = nullptr; const int32_t* u = nullptr; int64_t nnz = 0;
   int32_t traceCap = 0;
@@ -52,7 +52,8 @@ class SamplerCore {
     if (bd->n < 1 || bd->p < 1) throw std::invalid_argument("bart data must have n >= 1, p >= 1");
     if (bc->n_trees < 1) throw std::invalid_argument("n_trees must be >= 1");
     if (!(cc->sigma_init > 0)) throw std::invalid_argument("sigma_init must be > 0");
-    if (cc->is_binary || sd->is_binary) throw std::invalid_argument("binary (probit) responses are not supported by the device path yet");
+    if ((cc->is_binary != 0) != (sd->is_binary != 0)) throw std::invalid_argument("common_control.is_binary and stan_data.is_binary disagree");
+    binary_ = cc->is_binary != 0;
     if (sd->has_weights) throw std::invalid_argument("weights are not supported by the device path yet");
     if (sd->has_intercept) throw std::invalid_argument("has_intercept = 1 is not supported (BART supplies the intercept)");
     if (sd->prior_dist < 0 || sd->prior_dist > 2) throw std::invalid_argument("prior_dist must be 0, 1 or 2");
@@ -69,7 +70,7 @@ class SamplerCore {
     // ---- Stan spec + host copies of the design (the reference copies them too: stan_sampler.cpp:197-249)
     StanSpec sp;
     sp.N = sd->N; sp.K = sd->K; sp.q = sd->q; sp.t = sd->t; sp.len_theta_L = sd->len_theta_L;
-    sp.is_binary = 0; sp.prior_dist = sd->prior_dist; sp.prior_dist_for_aux = sd->prior_dist_for_aux;
+    sp.is_binary = binary_ ? 1 : 0; sp.prior_dist = sd->prior_dist; sp.prior_dist_for_aux = sd->prior_dist_for_aux;
     if (sd->K) { sp.prior_scale.assign(sd->prior_scale, sd->prior_scale + sd->K); sp.prior_mean.assign(sd->prior_mean, sd->prior_mean + sd->K);
                  sp.prior_df.assign(sd->prior_df, sd->prior_df + sd->K); }
     sp.prior_scale_for_aux = sd->prior_scale_for_aux; sp.prior_mean_for_aux = sd->prior_mean_for_aux; sp.prior_df_for_aux = sd->prior_df_for_aux;
@@ -117,7 +118,7 @@ class SamplerCore {
       di.model.pgDepth = pgDepth_.data(); di.model.logPg = logPg_.data(); di.model.log1mPg = log1mPg_.data();
       di.model.logInt = logInt_.data(); di.model.logIntLen = (int32_t)logInt_.size();
     }
-    di.K = K_; di.q = q_; di.X = sd->X; di.w = sd->w; di.v = sd->v; di.u = sd->u; di.nnz = sd->num_non_zero;
+    di.K = K_; di.q = q_; di.binary = binary_ ? 1 : 0; di.X = sd->X; di.w = sd->w; di.v = sd->v; di.u = sd->u; di.nnz = sd->num_non_zero;
     di.traceCap = 1 << 16;
     hostModelView_ = di.model; hostModelView_.numCuts = numCuts_.data();   // (table pointers are host pointers)
     dev_.init(di);
@@ -147,8 +148,7 @@ class SamplerCore {
     } else if (boi) bartOffset.assign(boi, boi + n_);
     dev_.offset_from_host(bartOffset.data());
     dev_.rescale(true);
-    dev_.set_sigma(cc->sigma_init);
-    sigma_ = cc->sigma_init;
+    if (!binary_) { dev_.set_sigma(cc->sigma_init); sigma_ = cc->sigma_init; } else sigma_ = 1.0;
     sample_trees_from_prior();
     dev_.sweep(thin_);
     treeUpdates_ += (long)T_ * thin_;
@@ -180,8 +180,7 @@ class SamplerCore {
           case OFFSET_FIXEF: dev_.offset_from_params(beta, b, 0, 1, 1); break;
           case OFFSET_PARAMETRIC: dev_.offset_from_params(beta, b, 0, 0, 1); break;
         }
-        sigma_ = cons[model_->sp.aux_pos()];
-        dev_.set_sigma(sigma_);
+        if (!binary_) { sigma_ = cons[model_->sp.aux_pos()]; dev_.set_sigma(sigma_); }
         if (out && out->stan) std::memcpy(out->stan + slot * (size_t)numPars, row_.data(), (size_t)numPars * sizeof(double));
         int update_scale_mod = 1 << (8 * iter / numIter);
         dev_.rescale(isWarmup && iter % update_scale_mod == 0);
@@ -219,7 +218,7 @@ class SamplerCore {
     std::string o = "lp__\naccept_stat__\nstepsize__\ntreedepth__\nn_leapfrog__\ndivergent__\nenergy__";
     auto add = [&](const char* base, int cnt) { for (int i = 1; i <= cnt; ++i) o += "\n" + std::string(base) + "." + std::to_string(i); };
     add("z_beta", m.K); add("z_b", m.q); add("z_T", m.len_z_T); add("rho", m.len_rho); add("zeta", m.len_conc); add("tau", m.t);
-    add("aux_unscaled", 1); add("aux", 1);
+    if (!m.is_binary) { add("aux_unscaled", 1); add("aux", 1); }
     add("beta", m.K); add("b", m.q); add("theta_L", m.len_theta_L);
     return o;
   }
@@ -387,7 +386,7 @@ class SamplerCore {
 
   Dev dev_;
   size_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 256, thin_ = 1, K_ = 0, q_ = 0, hmcMode_ = 0;
-  int warmup_ = 0, verbose_ = 0, offsetType_ = 0; bool keepFits_ = true, hasUserOffset_ = false;
+  int warmup_ = 0, verbose_ = 0, offsetType_ = 0; bool keepFits_ = true, hasUserOffset_ = false, binary_ = false;
   std::vector<double> userOffset_;
   s4b_callback_fn callback_ = nullptr; void* callbackUser_ = nullptr;
   MTState rng_;

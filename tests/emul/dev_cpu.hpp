@@ -17,7 +17,7 @@ class DevCpu {
  public:
   void init(const DevInit& d) {
     di_ = d;
-    n_ = (size_t)d.n; nTest_ = (size_t)d.nTest; P_ = d.P; T_ = d.T; nc_ = d.nc; K_ = d.K; q_ = d.q;
+    n_ = (size_t)d.n; nTest_ = (size_t)d.nTest; P_ = d.P; T_ = d.T; nc_ = d.nc; K_ = d.K; q_ = d.q; binary_ = d.binary != 0;
     xbin_.assign(d.xbin, d.xbin + (size_t)P_ * n_);
     if (nTest_) xbinTest_.assign(d.xbinTest, d.xbinTest + (size_t)P_ * nTest_);
     numCuts_.assign(d.numCuts, d.numCuts + P_);
@@ -69,6 +69,11 @@ class DevCpu {
     for (size_t i = 1; i < n_; ++i) { if (y_[i] < mn) mn = y_[i]; if (y_[i] > mx) mx = y_[i]; }
     scale_ = ScaleState{}; scale_.min = mn; scale_.max = mx; scale_.range = mx - mn; scale_.min0 = mn; scale_.range0 = mx - mn; scale_.sigmaData = 1.0; scale_.sigma = 1.0 / (mx - mn);
     for (size_t i = 0; i < n_; ++i) R_[i] = (y_[i] - mn) / scale_.range - 0.5;
+    if (binary_) {   // probit: no rescaling, sigma = 1, latents start at 2y - 1 (stored with the offset removed)
+      scale_.min = -0.5; scale_.max = 0.5; scale_.range = 1.0; scale_.min0 = -0.5; scale_.range0 = 1.0; scale_.sigmaData = 1.0; scale_.sigma = 1.0;
+      lat_.assign(n_, 0.0);
+      for (size_t i = 0; i < n_; ++i) { lat_[i] = 2.0 * y_[i] - 1.0; R_[i] = lat_[i]; }
+    }
   }
 
   void upload_rng(const MTState& s) { rng_ = s; }
@@ -116,7 +121,13 @@ class DevCpu {
     }
   }
   void set_sigma(double s) { scale_.sigmaData = s; scale_.sigma = s / scale_.range; }
+  void get_latents(double* out) { for (size_t i = 0; i < n_; ++i) out[i] = lat_[i] + off_[i]; }
   void rescale(bool update) {
+    if (binary_) {   // keep latent + offset invariant
+      for (size_t i = 0; i < n_; ++i) { double nl = lat_[i] + (off_[i] - offNew_[i]); R_[i] += nl - lat_[i]; lat_[i] = nl; }
+      off_.swap(offNew_); a_.off = off_.data(); a_.offNew = offNew_.data();
+      return;
+    }
     ScaleState& s = scale_;
     s.min0 = s.min; s.range0 = s.range; s.shiftPerTree = 0.0;
     if (update) {
@@ -140,7 +151,7 @@ class DevCpu {
 
   // ---- trees
   void assign_leaves_and_residual() {
-    for (size_t i = 0; i < n_; ++i) R_[i] = (y_[i] - off_[i] - scale_.min) / scale_.range - 0.5;
+    for (size_t i = 0; i < n_; ++i) R_[i] = binary_ ? lat_[i] : (y_[i] - off_[i] - scale_.min) / scale_.range - 0.5;
     for (int t = 0; t < T_; ++t) {
       TreeView tv = tree_view(a_, t);
       for (size_t i = 0; i < n_; ++i) {
@@ -159,6 +170,26 @@ class DevCpu {
         control_step(a_, t, t + 1 < T_ ? t + 1 : -1); ++launches_;
         apply(t); ++launches_;
       }
+      if (binary_) sample_latents();
+    }
+  }
+  // dbarts probit step: z_i ~ N(fit_i + offset_i, 1) truncated by y_i, sequential draws from R's generator
+  double lower_trunc_std_normal(double lower) {
+    double x;
+    if (lower < 0.0) { x = r_norm(&rng_); while (x < lower) x = r_norm(&rng_); }
+    else {
+      double a = 0.5 * (lower + std::sqrt(lower * lower + 4.0)), u, r;
+      do { x = r_exp(&rng_) / a + lower; u = r_unif(&rng_); double d = x - a; r = std::exp(-0.5 * d * d); } while (u > r);
+    }
+    return x;
+  }
+  void sample_latents() {
+    for (size_t i = 0; i < n_; ++i) {
+      double F = lat_[i] - R_[i];
+      double mean = F + off_[i];
+      double z = (y_[i] > 0.0) ? mean + lower_trunc_std_normal(0.0 - mean) : mean - lower_trunc_std_normal(mean - 0.0);
+      lat_[i] = z - off_[i];
+      R_[i] = lat_[i] - F;
     }
   }
   void profile_sweep(int nSweeps, int thin, double* out) { for (int i = 0; i < 8; ++i) out[i] = 0.0; for (int k = 0; k < nSweeps; ++k) sweep(thin); }
@@ -171,7 +202,7 @@ class DevCpu {
         while (tv.var.get(nd) >= 0) nd = (xbinTest_[(size_t)tv.var.get(nd) * nTest_ + i] <= tv.cut.get(nd)) ? tv.left.get(nd) : tv.right.get(nd);
         f += mu_[(size_t)t * nc_ + nd];
       }
-      out[i] = (f + 0.5) * scale_.range + scale_.min;
+      out[i] = binary_ ? f : (f + 0.5) * scale_.range + scale_.min;
     }
   }
 
@@ -181,13 +212,13 @@ class DevCpu {
     for (int k = 0; k < K_; ++k) cX[k] = 0.0;
     for (int j = 0; j < q_; ++j) cZ[j] = 0.0;
     for (size_t i = 0; i < n_; ++i) {
-      double fit = 0.0;
+      double fit = 0.0, resp = y_[i];
       if (mode != 0) {
-        double yr = (y_[i] - off_[i] - scale_.min) / scale_.range - 0.5;
-        fit = ((yr - R_[i]) + 0.5) * scale_.range + scale_.min;
+        if (binary_) { fit = lat_[i] - R_[i]; resp = lat_[i] + off_[i]; }   // Stan's response is the latent incl. the offset
+        else { double yr = (y_[i] - off_[i] - scale_.min) / scale_.range - 0.5; fit = ((yr - R_[i]) + 0.5) * scale_.range + scale_.min; }
       }
       double so = mode == 0 ? 0.0 : mode == 1 ? fit : mode == 2 ? user_[i] : fit + user_[i];
-      double e = y_[i] - so;
+      double e = resp - so;
       e0_[i] = e;
       ss += e * e;
       for (int k = 0; k < K_; ++k) cX[k] += X_[(size_t)k * n_ + i] * e;
@@ -256,7 +287,7 @@ class DevCpu {
   size_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0;
   std::vector<uint16_t> xbin_, xbinTest_, leaf_, cut_;
   std::vector<int32_t> numCuts_, cnt_, hwm_, v_, u_;
-  std::vector<double> y_, user_, X_, w_, R_, off_, offNew_, e0_, mu_, binCnt_, binSum_;
+  std::vector<double> y_, user_, X_, w_, R_, off_, offNew_, e0_, mu_, binCnt_, binSum_, lat_; bool binary_ = false;
   std::vector<int16_t> var_, left_, right_, parent_, cna_, cdep_, cleaf_, cpre_, cpost_;
   std::vector<int32_t> cnl_, cni_, cvalid_; std::vector<double> clogpi_;
   Scratch sc_[2];

@@ -94,8 +94,8 @@ def test_error_reporting(emul_lib):
     with pytest.raises(RuntimeError, match="node_capacity|node capacity"):
         run_chain(emul_lib, "emu_", args)
     args, _ = friedman_case()
-    args.is_binary = True
-    with pytest.raises(RuntimeError, match="binary"):
+    args.weights = np.ones(100) * 2.0
+    with pytest.raises(RuntimeError, match="weights"):
         run_chain(emul_lib, "emu_", args)
 
 
@@ -133,3 +133,18 @@ def test_product_sources_do_not_reference_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in text and "oracle/" not in text and "import oracle" not in text, os.path.join(dirpath, f)
                 assert "libs4b_emul" not in text and "dev_cpu" not in text, os.path.join(dirpath, f)
+
+
+@pytest.mark.parametrize("ranef", [True, False])
+def test_probit_emulated_product_matches_oracle(oracle_lib, emul_lib, ranef):
+    """binary response / probit link: latents from R's sequential stream (dbarts sampleProbitLatentVariables)."""
+    from stan4bart_amd import GroupTerm, generate_friedman_data, make_sampler_args
+    d = generate_friedman_data(200, ranef=ranef, causal=True, binary=True)
+    x = d["x"]
+    groups = [GroupTerm(d["g1"], None), GroupTerm(d["g2"], None)] if ranef else []
+    args = make_sampler_args(d["y"], x[:, [0, 1, 2, 4, 5, 6, 7, 8, 9]], X=np.column_stack([x[:, 3], d["z"]]), groups=groups,
+                             family="binomial", iter=13, warmup=7, bart_args={"n.trees": 11})
+    a = run_chain(oracle_lib, "orc_", args)
+    b = run_chain(emul_lib, "emu_", args)
+    assert_chain_parity(a, b)
+    assert "aux.1" not in a["names"] and a["names"] == b["names"]
