@@ -64,8 +64,10 @@ __device__ __forceinline__ double wave_max(double v) {
 // observation: R 8+8, leaf(t-1) 2, leaf(t) 2, binned predictor 2).
 // Per-node tables live in LDS as packed 16-byte records (one ds_read_b128 per observation and half).
 struct __attribute__((aligned(16))) NodeS { double mu; int16_t binA, binB; int16_t insub; int16_t pad; };   // stats half
-struct __attribute__((aligned(16))) NodeP { int16_t var; uint16_t cut; int16_t left, right; };               // 8 B: routing
+struct __attribute__((aligned(8))) NodeP { int16_t var; uint16_t cut; int16_t left, right; };                // 8 B: routing
+static_assert(sizeof(NodeS) == 16 && sizeof(NodeP) == 8, "LDS record sizes are part of the carve layout");
 struct __attribute__((aligned(16))) NodeA { double muOld, muNew; };                                           // apply half
+static_assert(sizeof(NodeA) == 16, "LDS record sizes are part of the carve layout");
 
 typedef unsigned short us4_t __attribute__((ext_vector_type(4)));
 static size_t apply_lds_bytes(int nc) { return (size_t)nc * 25 + 16; }

@@ -158,3 +158,14 @@ def test_probit_matches_oracle(oracle_lib, hip_lib, kw):
     b = run_chain(hip_lib, "s4b_", args)
     assert_chain_parity(a, b)
     assert np.all(a["sample"]["bart"]["sigma"] == 1.0) and "aux.1" not in b["names"]
+
+
+def test_trees_with_more_than_128_node_slots(oracle_lib, hip_lib):
+    """regression: the LDS records of k_tree are carved by size; a tree that uses > 128 node slots exercises the
+    upper half of every table (control code takes the global-memory path there: > 64 slots)."""
+    args, _ = friedman_case(n=4000, T=2, warmup=10, iter=30, ranef=False, bart_args={"base": 0.99, "power": 0.25, "k": 0.3})
+    args.node_capacity = 1024
+    a = run_chain(oracle_lib, "orc_", args, results_type=1)
+    b = run_chain(hip_lib, "s4b_", args, results_type=1)
+    assert a["trace"][:, 4].max() > 128
+    assert_chain_parity(a, b, stan=False)
