@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--p", type=int, default=50)
     ap.add_argument("--trees", type=int, default=200)
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-sweeps", type=int, default=2)
     a = ap.parse_args()
@@ -132,6 +132,14 @@ def main():
         dom, dom_us, dom_bytes = "k_tree", prof["stats_us"], 22.0 * n
         achieved = dom_bytes / (dom_us * 1e-6) / 1e9
         tree_update_us = prof["stats_us"] + prof["control_us"]
+        # HBM traffic of the same kernel from the PMC passes committed under profiles/ (rocprofv3 cannot wrap this process
+        # from inside; the counters were collected on the same command line, see profiles/pmc_traffic.json)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = json.load(f).get(str(n), {}).get("bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         rec = {
             "metric": "gibbs_iters_per_sec", "value": per_chain * world, "unit": "Gibbs iterations/s (all chains)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt_max / a.steps,
@@ -141,7 +149,7 @@ def main():
                        "chains": world, "hmc_mode": "sufficient-statistics", "n_leapfrog_timed": int(c1[0] - c0[0]),
                        "tree_updates_timed": int(c1[1] - c0[1]), "sigma_last": [float(s[0]) for s in sig]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
                          "tree_update": {"k_tree_us": prof["stats_us"], "k_control_us": prof["control_us"],
                                          "final_k_apply_us": prof["apply_us"], "algorithmic_bytes": 22.0 * n,

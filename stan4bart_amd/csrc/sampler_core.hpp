@@ -349,16 +349,22 @@ class SamplerCore {
     for (int t = 0; t < T_; ++t) { TreeView tv = h.view(t, nc_); int nd, k; Walker<TreeView> w(tv, 0); while (w.next(nd, k)) if (k == 1) ++out[tv.var.get(nd)]; }
   }
 
-  // G = [X Z]'[X Z]: constant over the whole run (hmc_mode 0)
+  // G = [X Z]'[X Z]: constant over the whole run (hmc_mode 0).  Z'Z is block-sparse (levels of one grouping
+  // factor never co-occur), so G is kept in CSR form: a leapfrog costs O(nnz(G)), not O((K+q)^2).
   void build_gram(const s4b_stan_data* sd) {
     const int M = K_ + q_;
-    gram_.assign((size_t)M * M, 0.0);
+    std::vector<double> dense((size_t)M * M, 0.0);
     std::vector<int> idx; std::vector<double> val;
     for (int64_t i = 0; i < sd->N; ++i) {
       idx.clear(); val.clear();
       for (int k = 0; k < K_; ++k) { idx.push_back(k); val.push_back(sd->X[(size_t)k * sd->N + i]); }
       if (q_) for (int e = sd->u[i]; e < sd->u[i + 1]; ++e) { idx.push_back(K_ + sd->v[e]); val.push_back(sd->w[e]); }
-      for (size_t a = 0; a < idx.size(); ++a) for (size_t b = 0; b < idx.size(); ++b) gram_[(size_t)idx[a] * M + idx[b]] += val[a] * val[b];
+      for (size_t a = 0; a < idx.size(); ++a) for (size_t b = 0; b < idx.size(); ++b) dense[(size_t)idx[a] * M + idx[b]] += val[a] * val[b];
+    }
+    gramPtr_.assign((size_t)M + 1, 0); gramCol_.clear(); gram_.clear();
+    for (int a = 0; a < M; ++a) {
+      for (int b = 0; b < M; ++b) if (dense[(size_t)a * M + b] != 0.0) { gramCol_.push_back(b); gram_.push_back(dense[(size_t)a * M + b]); }
+      gramPtr_[(size_t)a + 1] = (int)gramCol_.size();
     }
   }
   // ss = |e|^2, gX = X'e, gZ = Z'e with e = (y - offset) - X beta - Z b
@@ -368,9 +374,7 @@ class SamplerCore {
     double ss = s0_;
     for (int a = 0; a < M; ++a) {
       double ga = 0.0;
-      const double* row = &gram_[(size_t)a * M];
-      for (int k = 0; k < K_; ++k) ga += row[k] * beta[k];
-      for (int j = 0; j < q_; ++j) ga += row[K_ + j] * b[j];
+      for (int e = gramPtr_[(size_t)a]; e < gramPtr_[(size_t)a + 1]; ++e) { const int c = gramCol_[(size_t)e]; ga += gram_[(size_t)e] * (c < K_ ? beta[c] : b[c - K_]); }
       double ca = a < K_ ? cX_[(size_t)a] : cZ_[(size_t)(a - K_)];
       double th = a < K_ ? beta[a] : b[a - K_];
       ss += th * (ga - 2.0 * ca);
@@ -394,7 +398,7 @@ class SamplerCore {
   std::vector<double> pgDepth_, logPg_, log1mPg_, logInt_;
   ModelView hostModelView_;
   std::unique_ptr<HostModel> model_; std::unique_ptr<Nuts> nuts_;
-  std::vector<double> row_, cX_, cZ_, gram_; double s0_ = 0, sigma_ = 1;
+  std::vector<double> row_, cX_, cZ_, gram_; std::vector<int> gramPtr_, gramCol_; double s0_ = 0, sigma_ = 1;
   long treeUpdates_ = 0;
 };
 

@@ -65,6 +65,8 @@ inline TV texp(TV a) { double e = std::exp(a.v()); return {a.t, a.t->un(a.i, e, 
 inline TV tlog(TV a) { return {a.t, a.t->un(a.i, std::log(a.v()), 1.0 / a.v())}; }
 inline TV tsquare(TV a) { return {a.t, a.t->un(a.i, a.v() * a.v(), 2 * a.v())}; }
 inline TV tlog1m(TV a) { return {a.t, a.t->un(a.i, std::log1p(-a.v()), -1.0 / (1.0 - a.v()))}; }
+// log N(z | 0, 1) as one node
+inline TV tstd_normal_lpdf(TV z) { return {z.t, z.t->un(z.i, -0.5 * z.v() * z.v() - 0.91893853320467274178, -z.v())}; }
 
 // ---------------------------------------------------------------- model description (the stanData list)
 struct StanSpec {
@@ -104,16 +106,19 @@ class HostModel {
   long gradEvals = 0;
   explicit HostModel(const StanSpec& s) : sp(s) { sp.finish(); }
 
-  struct Fwd { TV sigma; std::vector<TV> beta, b, theta_L, constrained; TV lp; };
+  struct Fwd { TV sigma; std::vector<TV> beta, b, theta_L, constrained; TV lp; bool wantConstrained = true; };
 
   void forward(Tape& tp, const std::vector<double>& qv, Fwd& F, std::vector<int>& qidx, bool jacobian) const {
     tp.clear();
+    tp.ops.reserve(4096);
     qidx.resize((size_t)sp.D);
     for (int i = 0; i < sp.D; ++i) qidx[(size_t)i] = tp.leaf(qv[(size_t)i]);
     auto Q = [&](int i) { return TV{&tp, qidx[(size_t)i]}; };
     TV lp{&tp, tp.leaf(0.0)};
     int pos = 0;
-    std::vector<TV> z_beta, z_b, z_T, rho, zeta, tau;
+    std::vector<TV>& z_beta = w_[0]; std::vector<TV>& z_b = w_[1]; std::vector<TV>& z_T = w_[2];
+    std::vector<TV>& rho = w_[3]; std::vector<TV>& zeta = w_[4]; std::vector<TV>& tau = w_[5];
+    for (auto& v : w_) v.clear();
     for (int k = 0; k < sp.K; ++k) z_beta.push_back(Q(pos++));
     for (int j = 0; j < sp.q; ++j) z_b.push_back(Q(pos++));
     for (int j = 0; j < sp.len_z_T; ++j) z_T.push_back(Q(pos++));
@@ -147,6 +152,7 @@ class HostModel {
     theta_L(tp, aux, tau, zeta, rho, z_T, F.theta_L);
     make_b(tp, z_b, F.theta_L, F.b);
     F.constrained.clear();
+    if (F.wantConstrained) {
     for (auto& x : z_beta) F.constrained.push_back(x);
     for (auto& x : z_b) F.constrained.push_back(x);
     for (auto& x : z_T) F.constrained.push_back(x);
@@ -154,6 +160,7 @@ class HostModel {
     for (auto& x : zeta) F.constrained.push_back(x);
     for (auto& x : tau) F.constrained.push_back(x);
     if (!sp.is_binary) F.constrained.push_back(aux_unscaled);
+    }
 
     const double HALF_LOG_2PI = 0.91893853320467274178;
     if (!sp.is_binary && sp.prior_dist_for_aux > 0 && sp.prior_scale_for_aux > 0) {
@@ -165,9 +172,9 @@ class HostModel {
         lp = lp + (tt + (std::lgamma((nu + 1.0) / 2.0) - std::lgamma(nu / 2.0) - 0.5 * std::log(nu * M_PI))) - log_half;
       } else lp = lp - aux_unscaled;
     }
-    if (sp.prior_dist == 1 || sp.prior_dist == 2) for (auto& z : z_beta) lp = lp + (tsquare(z) * -0.5 - HALF_LOG_2PI);
-    for (auto& z : z_b) lp = lp + (tsquare(z) * -0.5 - HALF_LOG_2PI);
-    for (auto& z : z_T) lp = lp + (tsquare(z) * -0.5 - HALF_LOG_2PI);
+    if (sp.prior_dist == 1 || sp.prior_dist == 2) for (auto& z : z_beta) lp = lp + tstd_normal_lpdf(z);
+    for (auto& z : z_b) lp = lp + tstd_normal_lpdf(z);
+    for (auto& z : z_T) lp = lp + tstd_normal_lpdf(z);
     int pos_reg = 0, pos_rho = 0;
     for (int i = 0; i < sp.t; ++i) if (sp.p[(size_t)i] > 1) {
       int m = sp.p[(size_t)i] - 1;
@@ -189,9 +196,11 @@ class HostModel {
 
   double log_prob_grad(const std::vector<double>& qv, std::vector<double>& grad) {
     ++gradEvals;
-    Fwd F; std::vector<int> qidx;
+    Fwd& F = fwd_; std::vector<int>& qidx = qidx_;
+    F.wantConstrained = false;
     forward(tape_, qv, F, qidx, true);
-    std::vector<double> beta((size_t)sp.K), b((size_t)sp.q), gX((size_t)sp.K, 0.0), gZ((size_t)sp.q, 0.0);
+    std::vector<double>& beta = bufBeta_; std::vector<double>& b = bufB_; std::vector<double>& gX = bufGX_; std::vector<double>& gZ = bufGZ_;
+    beta.resize((size_t)sp.K); b.resize((size_t)sp.q); gX.assign((size_t)sp.K, 0.0); gZ.assign((size_t)sp.q, 0.0);
     for (int k = 0; k < sp.K; ++k) beta[(size_t)k] = F.beta[(size_t)k].v();
     for (int j = 0; j < sp.q; ++j) b[(size_t)j] = F.b[(size_t)j].v();
     double sigma = F.sigma.v();
@@ -212,6 +221,7 @@ class HostModel {
   // write_array_impl (continuous.hpp:2640-2938): constrained params, then aux, beta, b, theta_L
   void write_array(const std::vector<double>& qv, double* out) {
     Fwd F; std::vector<int> qidx;
+    F.wantConstrained = true;
     forward(tape_, qv, F, qidx, false);
     int o = 0;
     for (auto& x : F.constrained) out[o++] = x.v();
@@ -223,6 +233,8 @@ class HostModel {
 
  private:
   Tape tape_;
+  mutable std::vector<TV> w_[6];
+  Fwd fwd_; std::vector<int> qidx_; std::vector<double> bufBeta_, bufB_, bufGX_, bufGZ_;
   static TV cornish_fisher(TV z, double df) {
     TV z2 = tsquare(z), z3 = z2 * z, z5 = z2 * z3, z7 = z2 * z5, z9 = z2 * z7;
     double df2 = df * df, df3 = df2 * df, df4 = df2 * df2;
