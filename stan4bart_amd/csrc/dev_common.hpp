@@ -107,7 +107,8 @@ S4B_HD inline void control_step(const BartArrays& a, int t, int proposeNext) {
   StepRecord rec;
   TreeCache ca = tree_cache(a, t);
   a.hwm[t] = decide(cur, mu, cnt, muOld, a.hwm[t], a.model, a.scale->sigma, a.rng, c.prop, tb, binCnt, binSum, wk, c.accepted,
-                    a.traceOn ? &rec : nullptr, a.cvalid + t, ca);
+                    a.traceOn ? &rec : nullptr, ca);
+  a.cnl[t] = ca.nl; a.cni[t] = ca.ni; a.clogpi[t] = ca.logPi;   // (lists are written in place)
   if (a.traceOn) push_trace(a, rec);
   if (proposeNext >= 0) propose_step(a, proposeNext);
 }

@@ -350,7 +350,8 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
   tbT.prop.var.r = cT.pvar[li]; tbT.prop.cut.r = cT.pcut[li]; tbT.prop.left.r = cT.pleft[li]; tbT.prop.right.r = cT.pright[li];
   tbT.prop.parent.r = cT.pparent[li]; tbT.prop.na.r = cT.pna[li]; tbT.prop.dep.r = cT.pdep[li]; tbT.prop.nc = curT.nc;
   tbT.binA.r = cT.binA[li]; tbT.binB.r = cT.binB[li]; tbT.insub.r = cT.insub[li]; tbT.list.r = 0;
-  caT.leaf.r = a.cleaf[oT + li]; caT.pre.r = 0; caT.post.r = 0; caT.nl = cnlT; caT.ni = 0; caT.logPi = 0.0; caT.valid = cvalidT;
+  caT.leaf.r = a.cleaf[oT + li]; caT.pre.r = a.cpre[oT + li]; caT.post.r = a.cpost[oT + li]; caT.nl = cnlT; caT.ni = a.cni[tt];
+  caT.logPi = a.clogpi[tt]; caT.valid = cvalidT;
   mu.load(a.mu[oT + li]); muOld.load(0.0); cnt.r = a.cnt[oT + li];
   curN.var.r = a.var[oN + li]; curN.cut.r = a.cut[oN + li]; curN.left.r = a.left[oN + li]; curN.right.r = a.right[oN + li];
   curN.parent.r = a.parent[oN + li]; curN.na.r = a.cna[oN + li]; curN.dep.r = a.cdep[oN + li]; curN.nc = curT.nc;
@@ -422,14 +423,18 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
     binCnt.load(lane < nb ? ((s_red[1][0][lane] + s_red[1][1][lane]) + s_red[1][2][lane]) + s_red[1][3][lane] : 0.0);
     DecideWork<WaveArrD> wk;
     wk.ll.load(0.0); wk.lc.load(0.0); wk.ls.load(0.0); wk.u1.load(0.5); wk.u2.load(0.5); wk.val.load(0.0);
-    StepRecord rec; int32_t accepted = 0; int32_t cacheValid = cvalidT;
-    const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &s_rng, &s_prT, tbT, binCnt, binSum, wk, &accepted, &rec, &cacheValid, caT);
+    StepRecord rec; int32_t accepted = 0;
+    const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &s_rng, &s_prT, tbT, binCnt, binSum, wk, &accepted, &rec, caT);
     const int cntOut = prT.hwm > hwmNew ? prT.hwm : hwmNew;
     wave_tree_store(curT, a.var + oT, a.cut + oT, a.left + oT, a.right + oT, a.parent + oT, cntOut, lane);
     if (lane < cntOut) { a.mu[oT + lane] = mu.mine(); a.cnt[oT + lane] = cnt.r; cT.muOld[lane] = muOld.mine(); cT.insub[lane] = (uint8_t)tbT.insub.r; }
+    if (accepted) {   // the structure cache moved with the tree: keep the global copy current
+      if (lane < cntOut) { a.cna[oT + lane] = (int16_t)curT.na.r; a.cdep[oT + lane] = (int16_t)curT.dep.r; }
+      if (laneIn) { a.cleaf[oT + lane] = (int16_t)caT.leaf.r; a.cpre[oT + lane] = (int16_t)caT.pre.r; a.cpost[oT + lane] = (int16_t)caT.post.r; }
+      if (lane == 0) { a.cnl[t] = caT.nl; a.cni[t] = caT.ni; a.clogpi[t] = caT.logPi; }
+    }
     if (lane == 0) {
       a.hwm[t] = hwmNew; *cT.accepted = accepted;
-      if (cacheValid != cvalidT) a.cvalid[t] = cacheValid;
       if (a.traceOn) push_trace(a, rec);
     }
   }
@@ -793,6 +798,8 @@ class DevHip {
  public:
   DevHip() {}
   ~DevHip() {
+    if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
     for (void* p : allocs_) (void)hipFree(p);
     if (pinned_) (void)hipHostFree(pinned_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -808,6 +815,7 @@ class DevHip {
     if (d.device < 0 || d.device >= count) throw std::runtime_error("stan4bart_amd: HIP device ordinal out of range");
     device_ = d.device;
     HIP_OK(hipSetDevice(device_));
+    if (const char* g = getenv("S4B_GRAPH")) useGraph_ = atoi(g) != 0;
     HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     HIP_OK(hipEventCreate(&evStart_)); HIP_OK(hipEventCreate(&evStop_));
     n_ = d.n; nTest_ = d.nTest; P_ = d.P; T_ = d.T; nc_ = d.nc; K_ = d.K; q_ = d.q;
@@ -974,7 +982,41 @@ class DevHip {
 
   // ---- trees
   void assign_leaves_and_residual() { hipLaunchKernelGGL(k_assign_leaves, dim3(gridN_), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+  // One sweep = 2 T + 2 launches with arguments that never change (per-tree state is reached through pointers), so
+  // it is captured once into a hipGraph and replayed: the host then costs one call per sweep instead of ~4 us per launch.
   void sweep(int thin) {
+    static const bool dbg = getenv("S4B_HOST_TIMING") != nullptr;
+    if (dbg) HIP_OK(hipEventRecord(evStart_, stream_));
+    sweep_impl(thin);
+    if (dbg) {
+      HIP_OK(hipEventRecord(evStop_, stream_)); sync();
+      float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_)); dbgSweepMs_ += ms; ++dbgSweeps_;
+      if (dbgSweeps_ % 20 == 0) fprintf(stderr, "S4B in-loop sweep GPU time: %.3f ms avg over %d\n", dbgSweepMs_ / dbgSweeps_, dbgSweeps_);
+    }
+  }
+  void sweep_impl(int thin) {
+    if (useGraph_) {
+      if (!graphExec_ || graphTrace_ != a_.traceOn) capture_sweep();
+      for (int k = 0; k < thin; ++k) {
+        HIP_OK(hipGraphLaunch(graphExec_, stream_)); launches_ += 2 * T_ + 2;
+        if (binary_) { hipLaunchKernelGGL(k_latents, dim3(1), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+      }
+      return;
+    }
+    sweep_eager(thin, true);
+  }
+  void capture_sweep() {
+    if (graphExec_) { (void)hipGraphExecDestroy(graphExec_); graphExec_ = nullptr; }
+    if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
+    HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    const int64_t before = launches_;
+    sweep_eager(1, false);
+    launches_ = before;
+    HIP_OK(hipStreamEndCapture(stream_, &graph_));
+    HIP_OK(hipGraphInstantiate(&graphExec_, graph_, nullptr, nullptr, 0));
+    graphTrace_ = a_.traceOn;
+  }
+  void sweep_eager(int thin, bool withLatents) {
     for (int k = 0; k < thin; ++k) {
       // per tree: one fused O(N) kernel (finish tree t-1, statistics of tree t) + one control kernel
       hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsControl_, stream_, a_, -1, 0); ++launches_;
@@ -985,7 +1027,7 @@ class DevHip {
         launches_ += 2;
       }
       hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, T_ - 1); ++launches_;
-      if (binary_) { hipLaunchKernelGGL(k_latents, dim3(1), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+      if (binary_ && withLatents) { hipLaunchKernelGGL(k_latents, dim3(1), dim3(BLOCK), 0, stream_, a_); ++launches_; }
     }
   }
   // per-launch HIP-event timing of extra sweeps on the sampler's stream (bench.py roofline leg)
@@ -1119,6 +1161,8 @@ class DevHip {
   int device_ = 0; hipStream_t stream_ = nullptr; hipEvent_t evStart_ = nullptr, evStop_ = nullptr;
   int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1; bool binary_ = false;
   size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0;
+  double dbgSweepMs_ = 0; int dbgSweeps_ = 0;
+  hipGraph_t graph_ = nullptr; hipGraphExec_t graphExec_ = nullptr; int graphTrace_ = -1; bool useGraph_ = true;
   BartArrays a_; StanArrays s_;
   std::vector<void*> allocs_;
   double* pinned_ = nullptr; double* testOut_ = nullptr;

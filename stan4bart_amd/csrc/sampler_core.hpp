@@ -11,7 +11,9 @@
 #define S4B_SAMPLER_CORE_HPP
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -164,11 +166,19 @@ class SamplerCore {
     size_t slot = 0;
     std::vector<double> train, test;
     const bool wantTrain = (out && out->bart_train) || callback_;
+    // keep_fits = FALSE keeps one result slot that every iteration overwrites (reference src/init.cpp:725-733): without a
+    // callback only the last iteration's draw is observable, so nothing O(N) crosses PCIe before it
+    const bool lastOnly = !keepFits_ && !callback_;
     if (wantTrain) train.resize(n_);
     if (nTest_) test.resize(nTest_);
+    const bool timing = std::getenv("S4B_HOST_TIMING") != nullptr;
+    double tph[4] = {0, 0, 0, 0};
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int iter = 0; iter < numIter; ++iter) {
+      double t0 = timing ? now() : 0;
       if (doStan) {
         nuts_->run(row_.data());
+        if (timing) { tph[0] += now() - t0; t0 = now(); }
         const double* cons = row_.data() + 7;
         const double* beta = cons + model_->sp.beta_pos();
         const double* b = cons + model_->sp.b_pos();
@@ -184,22 +194,28 @@ class SamplerCore {
         if (out && out->stan) std::memcpy(out->stan + slot * (size_t)numPars, row_.data(), (size_t)numPars * sizeof(double));
         int update_scale_mod = 1 << (8 * iter / numIter);
         dev_.rescale(isWarmup && iter % update_scale_mod == 0);
+        if (timing) { tph[1] += now() - t0; t0 = now(); }
       }
       if (doBart) {
         dev_.sweep(thin_);
+        if (timing) { tph[2] += now() - t0; t0 = now(); }
         treeUpdates_ += (long)T_ * thin_;
-        dev_.stan_inputs(stan_mode(), wantTrain, cX_.data(), cZ_.data(), &s0_, wantTrain ? train.data() : nullptr);
-        if (nTest_ && ((out && out->bart_test) || callback_)) dev_.test_fits(test.data());
-        if (out) {
+        const bool emit = !lastOnly || iter == numIter - 1;
+        dev_.stan_inputs(stan_mode(), wantTrain && emit, cX_.data(), cZ_.data(), &s0_, (wantTrain && emit) ? train.data() : nullptr);
+        if (nTest_ && emit && ((out && out->bart_test) || callback_)) dev_.test_fits(test.data());
+        if (out && emit) {
           if (out->bart_sigma) out->bart_sigma[slot] = sigma_;
           if (out->bart_train) std::memcpy(out->bart_train + slot * n_, train.data(), n_ * sizeof(double));
           if (out->bart_test && nTest_) std::memcpy(out->bart_test + slot * nTest_, test.data(), nTest_ * sizeof(double));
           if (out->bart_varcount) var_counts(out->bart_varcount + slot * (size_t)P_);
         }
         if (callback_) callback_(callbackUser_, train.data(), nTest_ ? test.data() : nullptr, row_.data(), numPars);
+        if (timing) tph[3] += now() - t0;
       }
       if (keepFits_) ++slot;
     }
+    if (timing) std::fprintf(stderr, "S4B host ms/iter: nuts %.3f  offset+rescale issue %.3f  sweep issue %.3f  stan_inputs+wait %.3f\n",
+                             1e3 * tph[0] / numIter, 1e3 * tph[1] / numIter, 1e3 * tph[2] / numIter, 1e3 * tph[3] / numIter);
     check_device();
   }
 

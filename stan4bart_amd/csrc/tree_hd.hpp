@@ -548,7 +548,7 @@ struct DecideWork { AF64 ll, lc, ls, u1, u2, val; };
 template <class TR, class TBL, class AF64, class AI32, class ABIN, class CA>
 S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, const ModelView& m, double sigma, MTState* rng,
                          const Proposal* pr, TBL& tb, const ABIN& binCnt, const ABIN& binSum, DecideWork<AF64>& wk,
-                         int32_t* accepted, StepRecord* rec, int32_t* cacheValid, const CA& ca) {
+                         int32_t* accepted, StepRecord* rec, CA& ca) {
   TR& pt = tb.prop;
   sigma = S4B_UNI(sigma);
   const double sigma2 = sigma * sigma;
@@ -594,11 +594,41 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
     cDeath = binCnt.get(bl) + binCnt.get(br); sDeath = binSum.get(bl) + binSum.get(br);
     tb.insub.set(L, 1); tb.insub.set(R, 1);
   }
-  if (acc) { tv_copy(pt, cur, prHwm); hwm = prHwm; *cacheValid = 0; }
-  // DFS leaf list of the final tree: unchanged (cached) unless the move was accepted
-  const int nl = acc ? tv_list_leaves(cur, 0, tb.list) : ca.nl;
+  if (acc) {
+    // keep the structure cache in step with the accepted move instead of rebuilding it from scratch:
+    //   swap / change: same shape, the memo of the subtree was filled for the proposal, log prior = YLogPi
+    //   birth / death: three own terms of the log prior change; the node lists are re-walked once
+    if (prType == MOVE_SWAP || prType == MOVE_CHANGE) {
+      tv_copy(pt, cur, prHwm); hwm = prHwm;
+      ca.logPi = S4B_UNI(pr->YLogPi);
+    } else if (prType == MOVE_BIRTH) {
+      const int depthNd = tv_depth_of(cur, nd);
+      const double before = tv_log_prior_own(cur, m, nd, depthNd);
+      tv_copy(pt, cur, prHwm); hwm = prHwm;
+      const double after = tv_log_prior_own(cur, m, nd, depthNd) + tv_log_prior_own(cur, m, cur.left.get(nd), depthNd + 1) +
+                           tv_log_prior_own(cur, m, cur.right.get(nd), depthNd + 1);
+      ca.logPi = (ca.logPi - before) + after;
+    } else {
+      const int depthNd = tv_depth_of(cur, nd);
+      const double before = tv_log_prior_own(cur, m, nd, depthNd) + tv_log_prior_own(cur, m, cur.left.get(nd), depthNd + 1) +
+                            tv_log_prior_own(cur, m, cur.right.get(nd), depthNd + 1);
+      tv_copy(pt, cur, prHwm); hwm = prHwm;
+      ca.logPi = (ca.logPi - before) + tv_log_prior_own(cur, m, nd, depthNd);
+    }
+    if (prType == MOVE_BIRTH || prType == MOVE_DEATH) {
+      int nlw = 0, np = 0, nq = 0, wn, wk2; Walker<TR> w(cur, 0);
+      while (w.next(wn, wk2)) {
+        if (wk2 == 0) ca.leaf.set(nlw++, (int16_t)wn);
+        else if (wk2 == 1) ca.pre.set(np++, (int16_t)wn);
+        else ca.post.set(nq++, (int16_t)wn);
+      }
+      ca.nl = nlw; ca.ni = np;
+    }
+  }
+  // DFS leaf list of the tree we end up with (the cache is current either way)
+  const int nl = ca.nl;
   for (int i = 0; i < nl; ++i) {
-    int n = acc ? tb.list.get(i) : ca.leaf.get(i);
+    int n = ca.leaf.get(i);
     double lc, ls;
     if (deathAcc && n == nd) { lc = cDeath; ls = sDeath; }
     else {
@@ -610,7 +640,7 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
     if (lc != 0.0) { wk.u1.set(i, r_unif(rng)); wk.u2.set(i, r_unif(rng)); }
   }
   leaves_draw(wk.lc, wk.ls, wk.u1, wk.u2, nl, sigma2, m.leafPrec, wk.val);
-  for (int i = 0; i < nl; ++i) { int n = acc ? tb.list.get(i) : ca.leaf.get(i); cnt.set(n, (int32_t)wk.lc.get(i)); mu.set(n, wk.val.get(i)); }
+  for (int i = 0; i < nl; ++i) { int n = ca.leaf.get(i); cnt.set(n, (int32_t)wk.lc.get(i)); mu.set(n, wk.val.get(i)); }
   if (rec) { rec->type = prType; rec->status = prStatus == 1 ? acc : -1; rec->var = pr->var; rec->split = pr->split; rec->numLeaves = nl; }
   *accepted = acc;
   return hwm;
