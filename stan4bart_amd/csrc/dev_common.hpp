@@ -48,7 +48,7 @@ struct BartArrays {
   int16_t *var, *left, *right, *parent; uint16_t* cut; double* mu; int32_t* cnt; int32_t* hwm;
   // per-tree structure cache, [T][nc] / [T]: node memo (available predictors, depth), leaves in DFS order,
   // internal nodes in pre- and post-order, log tree prior; rebuilt lazily after an accepted move
-  int16_t *cna, *cdep, *cleaf, *cpre, *cpost; int32_t *cnl, *cni, *cvalid; double* clogpi;
+  int16_t *cna, *cdep, *cleaf, *cpre, *cpost; int32_t *cnl, *cni, *cg, *cgn, *cvalid; double* clogpi;
   // updates in flight: two scratch sets, tree t uses set (t & 1) so that the proposal of tree t+1 can be
   // drawn (same lane, same RNG stream position) while the apply pass of tree t still reads its tables
   StepScratch sc[2];
@@ -67,7 +67,7 @@ S4B_HD inline TreeView tree_view(const BartArrays& a, int t) {
 S4B_HD inline TreeCache tree_cache(const BartArrays& a, int t) {
   size_t o = (size_t)t * (size_t)a.nc;
   TreeCache c; c.leaf = PtrArr<int16_t>(a.cleaf + o); c.pre = PtrArr<int16_t>(a.cpre + o); c.post = PtrArr<int16_t>(a.cpost + o);
-  c.nl = a.cnl[t]; c.ni = a.cni[t]; c.logPi = a.clogpi[t]; c.valid = a.cvalid[t];
+  c.nl = a.cnl[t]; c.ni = a.cni[t]; c.g = a.cg[t]; c.gn = a.cgn[t]; c.logPi = a.clogpi[t]; c.valid = a.cvalid[t];
   return c;
 }
 S4B_HD inline StepTables step_tables(const BartArrays& a, int t) {
@@ -85,7 +85,7 @@ S4B_HD inline void propose_step(const BartArrays& a, int t) {
   StepTables tb = step_tables(a, t);
   const int hwm = a.hwm[t];
   TreeCache ca = tree_cache(a, t);
-  if (!ca.valid) { tv_rebuild_cache(cur, a.model, ca); a.cnl[t] = ca.nl; a.cni[t] = ca.ni; a.clogpi[t] = ca.logPi; a.cvalid[t] = 1; }
+  if (!ca.valid) { tv_rebuild_cache(cur, a.model, ca); a.cnl[t] = ca.nl; a.cni[t] = ca.ni; a.cg[t] = ca.g; a.cgn[t] = ca.gn; a.clogpi[t] = ca.logPi; a.cvalid[t] = 1; }
   tv_copy(cur, tb.prop, hwm);
   for (int i = 0; i < hwm; ++i) { tb.binA.set(i, -1); tb.binB.set(i, -1); tb.insub.set(i, 0); }
   if (propose(cur, hwm, a.model, a.rng, a.sc[t & 1].prop, tb, ca) != 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
@@ -108,7 +108,7 @@ S4B_HD inline void control_step(const BartArrays& a, int t, int proposeNext) {
   TreeCache ca = tree_cache(a, t);
   a.hwm[t] = decide(cur, mu, cnt, muOld, a.hwm[t], a.model, a.scale->sigma, a.rng, c.prop, tb, binCnt, binSum, wk, c.accepted,
                     a.traceOn ? &rec : nullptr, ca);
-  a.cnl[t] = ca.nl; a.cni[t] = ca.ni; a.clogpi[t] = ca.logPi;   // (lists are written in place)
+  a.cnl[t] = ca.nl; a.cni[t] = ca.ni; a.cg[t] = ca.g; a.cgn[t] = ca.gn; a.clogpi[t] = ca.logPi;   // (lists are written in place)
   if (a.traceOn) push_trace(a, rec);
   if (proposeNext >= 0) propose_step(a, proposeNext);
 }

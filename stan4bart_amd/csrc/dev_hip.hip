@@ -270,6 +270,10 @@ __device__ __forceinline__ void tv_copy(const WaveTree& src, WaveTree& dst, int)
   dst.var.r = src.var.r; dst.cut.r = src.cut.r; dst.left.r = src.left.r; dst.right.r = src.right.r; dst.parent.r = src.parent.r;
   dst.na.r = src.na.r; dst.dep.r = src.dep.r;
 }
+__device__ __forceinline__ void copy_leaf_values(const WaveArrD& mu, WaveArrD& muOld, int hwm, int) {
+  const bool in = (int)(threadIdx.x & 63) < hwm;
+  muOld.lo = in ? mu.lo : 0; muOld.hi = in ? mu.hi : 0;
+}
 // lane-parallel versions of the batched math of decide(): lane b / lane i owns bin b / leaf i
 __device__ __forceinline__ void bins_loglik(const WaveArrD& binCnt, const WaveArrD& binSum, int, double sigma2, double prec, WaveArrD& out) {
   const double c = binCnt.mine();
@@ -351,12 +355,12 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
   tbT.prop.parent.r = cT.pparent[li]; tbT.prop.na.r = cT.pna[li]; tbT.prop.dep.r = cT.pdep[li]; tbT.prop.nc = curT.nc;
   tbT.binA.r = cT.binA[li]; tbT.binB.r = cT.binB[li]; tbT.insub.r = cT.insub[li]; tbT.list.r = 0;
   caT.leaf.r = a.cleaf[oT + li]; caT.pre.r = a.cpre[oT + li]; caT.post.r = a.cpost[oT + li]; caT.nl = cnlT; caT.ni = a.cni[tt];
-  caT.logPi = a.clogpi[tt]; caT.valid = cvalidT;
+  caT.g = a.cg[tt]; caT.gn = a.cgn[tt]; caT.logPi = a.clogpi[tt]; caT.valid = cvalidT;
   mu.load(a.mu[oT + li]); muOld.load(0.0); cnt.r = a.cnt[oT + li];
   curN.var.r = a.var[oN + li]; curN.cut.r = a.cut[oN + li]; curN.left.r = a.left[oN + li]; curN.right.r = a.right[oN + li];
   curN.parent.r = a.parent[oN + li]; curN.na.r = a.cna[oN + li]; curN.dep.r = a.cdep[oN + li]; curN.nc = curT.nc;
   caN.leaf.r = a.cleaf[oN + li]; caN.pre.r = a.cpre[oN + li]; caN.post.r = a.cpost[oN + li];
-  caN.nl = cnlN; caN.ni = cniN; caN.logPi = clogpiN; caN.valid = cvalidN;
+  caN.nl = cnlN; caN.ni = cniN; caN.g = a.cg[tn]; caN.gn = a.cgn[tn]; caN.logPi = clogpiN; caN.valid = cvalidN;
   // partials of the first 8 bins (whether or not the proposal has that many: the grid-sized slabs exist)
   double ps[8], pc[8];
 #pragma unroll
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
     if (accepted) {   // the structure cache moved with the tree: keep the global copy current
       if (lane < cntOut) { a.cna[oT + lane] = (int16_t)curT.na.r; a.cdep[oT + lane] = (int16_t)curT.dep.r; }
       if (laneIn) { a.cleaf[oT + lane] = (int16_t)caT.leaf.r; a.cpre[oT + lane] = (int16_t)caT.pre.r; a.cpost[oT + lane] = (int16_t)caT.post.r; }
-      if (lane == 0) { a.cnl[t] = caT.nl; a.cni[t] = caT.ni; a.clogpi[t] = caT.logPi; }
+      if (lane == 0) { a.cnl[t] = caT.nl; a.cni[t] = caT.ni; a.cg[t] = caT.g; a.cgn[t] = caT.gn; a.clogpi[t] = caT.logPi; }
     }
     if (lane == 0) {
       a.hwm[t] = hwmNew; *cT.accepted = accepted;
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
       tv_rebuild_cache(curN, m, caN);
       if (laneIn) { a.cna[oN + lane] = (int16_t)curN.na.r; a.cdep[oN + lane] = (int16_t)curN.dep.r; a.cleaf[oN + lane] = (int16_t)caN.leaf.r;
                     a.cpre[oN + lane] = (int16_t)caN.pre.r; a.cpost[oN + lane] = (int16_t)caN.post.r; }
-      if (lane == 0) { a.cnl[next] = caN.nl; a.cni[next] = caN.ni; a.clogpi[next] = caN.logPi; a.cvalid[next] = 1; }
+      if (lane == 0) { a.cnl[next] = caN.nl; a.cni[next] = caN.ni; a.cg[next] = caN.g; a.cgn[next] = caN.gn; a.clogpi[next] = caN.logPi; a.cvalid[next] = 1; }
     }
     tbN.prop = curN;
     tbN.binA.r = -1; tbN.binB.r = -1; tbN.insub.r = 0; tbN.list.r = 0;
@@ -854,7 +858,8 @@ class DevHip {
     a.var = alloc<int16_t>(m); a.left = alloc<int16_t>(m); a.right = alloc<int16_t>(m); a.parent = alloc<int16_t>(m); a.cut = alloc<uint16_t>(m);
     a.mu = alloc<double>(m); a.cnt = alloc<int32_t>(m); a.hwm = alloc<int32_t>((size_t)T_);
     a.cna = zalloc<int16_t>(m); a.cdep = zalloc<int16_t>(m); a.cleaf = zalloc<int16_t>(m); a.cpre = zalloc<int16_t>(m); a.cpost = zalloc<int16_t>(m);
-    a.cnl = zalloc<int32_t>((size_t)T_); a.cni = zalloc<int32_t>((size_t)T_); a.cvalid = zalloc<int32_t>((size_t)T_); a.clogpi = zalloc<double>((size_t)T_);
+    a.cnl = zalloc<int32_t>((size_t)T_); a.cni = zalloc<int32_t>((size_t)T_); a.cg = zalloc<int32_t>((size_t)T_); a.cgn = zalloc<int32_t>((size_t)T_);
+    a.cvalid = zalloc<int32_t>((size_t)T_); a.clogpi = zalloc<double>((size_t)T_);
     {
       std::vector<int16_t> var(m, NODE_FREE), neg(m, -1); std::vector<int32_t> hwm((size_t)T_, 1);
       for (int t = 0; t < T_; ++t) var[(size_t)t * nc_] = NODE_LEAF;

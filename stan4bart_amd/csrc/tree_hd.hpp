@@ -311,10 +311,18 @@ struct TreeCacheT {
   AI16 pre;      // internal nodes, pre-order
   AI16 post;     // internal nodes, post-order
   int32_t nl, ni;
+  int32_t g, gn; // leaves that can still grow; internal nodes whose children are both leaves
   double logPi;  // log tree prior
   int32_t valid;
 };
 typedef TreeCacheT<PtrArr<int16_t>> TreeCache;
+
+template <class TR, class CA> S4B_HD inline void tv_recount(const TR& cur, const ModelView& m, CA& c) {
+  int g = 0, gn = 0;
+  for (int i = 0; i < c.nl; ++i) if (tv_num_avail(cur, m, c.leaf.get(i)) > 0) ++g;
+  for (int i = 0; i < c.ni; ++i) if (tv_is_nog(cur, c.pre.get(i))) ++gn;
+  c.g = g; c.gn = gn;
+}
 
 // (re)build memo + lists + log prior of `cur`
 template <class TR, class CA> S4B_HD inline void tv_rebuild_cache(TR& cur, const ModelView& m, CA& c) {
@@ -326,6 +334,7 @@ template <class TR, class CA> S4B_HD inline void tv_rebuild_cache(TR& cur, const
     else c.post.set(nq++, (int16_t)nd);
   }
   c.nl = nl; c.ni = np;
+  tv_recount(cur, m, c);
   c.logPi = tv_log_prior(cur, m);
   c.valid = 1;
 }
@@ -374,8 +383,7 @@ S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* r
   double u = r_unif(rng);
   if (u < m.pBD) {
     const bool single = ni == 0;
-    int g = 0;   // leaves that can still grow
-    if (single) g = 1; else for (int i = 0; i < nl; ++i) if (tv_num_avail(cur, m, ca.leaf.get(i)) > 0) ++g;
+    const int g = single ? 1 : ca.g;   // leaves that can still grow
     double pBirthStep = single ? 1.0 : (g > 0 ? m.pBirth : 0.0);
     if (r_unif(rng) < pBirthStep) {
       pr->type = MOVE_BIRTH;
@@ -409,8 +417,8 @@ S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* r
       int gNew = (single ? 0 : g - 1) + (naL > 0 ? 1 : 0) + (naR > 0 ? 1 : 0);
       double pDeath = 1.0 - (gNew > 0 ? m.pBirth : 0.0);
       // nodes whose children are both leaves, after the birth: the old ones, minus nd's parent if it was one, plus nd
-      int nog = 1;
-      for (int i = 0; i < ni; ++i) { int q = ca.pre.get(i); if (tv_is_nog(cur, q) && q != cur.parent.get(nd)) ++nog; }
+      int nog = ca.gn + 1;
+      { int par = cur.parent.get(nd); if (par >= 0 && tv_is_nog(cur, par)) --nog; }
       double pSelectDeath = 1.0 / (double)nog;
       pr->priorRatio = newPrior / oldPrior;
       pr->transRatio = (pDeath * pSelectDeath) / (pBirthStep * pSelect);
@@ -419,8 +427,7 @@ S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* r
       pr->status = 1;
     } else {
       pr->type = MOVE_DEATH;
-      int gn = 0;
-      for (int i = 0; i < ni; ++i) if (tv_is_nog(cur, ca.pre.get(i))) ++gn;
+      const int gn = ca.gn;
       if (gn == 0) return 0;
       int idx = r_unif_int(rng, 0, gn);
       int nd = 0;
@@ -518,6 +525,11 @@ S4B_HD inline double draw_leaf(double lc, double ls, double sigma2, double prec,
   return mean + sd * r_norm(rng);
 }
 
+// muOld[i] = i < hwm ? mu[i] : 0 for i < count (default: element by element)
+template <class AF64> S4B_HD inline void copy_leaf_values(const AF64& mu, AF64& muOld, int hwm, int count) {
+  for (int i = 0; i < count; ++i) muOld.set(i, (i < hwm) ? mu.get(i) : 0.0);
+}
+
 // batched math (defaults: element by element; the wave policy overloads them lane-parallel)
 template <class ABIN, class AOUT>
 S4B_HD inline void bins_loglik(const ABIN& binCnt, const ABIN& binSum, int nb, double sigma2, double prec, AOUT& out) {
@@ -554,26 +566,31 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
   const double sigma2 = sigma * sigma;
   int acc = 0;
   const int prHwm = S4B_UNI(pr->hwm), prType = S4B_UNI(pr->type), prStatus = S4B_UNI(pr->status), prNode = S4B_UNI(pr->node);
-  for (int i = 0; i < prHwm; ++i) muOld.set(i, (i < hwm) ? mu.get(i) : 0.0);
+  copy_leaf_values(mu, muOld, hwm, prHwm);
   const int nbAll = S4B_UNI(pr->nbA) + S4B_UNI(pr->nbB);
   if (prStatus == 1) {
     const int nd = prNode;
     bins_loglik(binCnt, binSum, nbAll, sigma2, m.leafPrec, wk.ll);
     double oldLL = 0.0, newLL = 0.0; bool oldEmpty = false, newEmpty = false;
-    int no = tv_list_leaves(cur, nd, tb.list);   // old branch: current leaves under nd, DFS order
-    for (int i = 0; i < no; ++i) {
-      int b = tb.binA.get(tb.list.get(i));
-      if (binCnt.get(b) == 0.0) oldEmpty = true; else oldLL += wk.ll.get(b);
-    }
-    if (prType == MOVE_DEATH) {
+    if (prType == MOVE_BIRTH) {          // old branch = the leaf itself, new branch = its two children (left, right)
+      int b0 = tb.binA.get(nd);
+      if (binCnt.get(b0) == 0.0) oldEmpty = true; else oldLL += wk.ll.get(b0);
+      int bl = tb.binB.get(pt.left.get(nd)), br = tb.binB.get(pt.right.get(nd));
+      if (binCnt.get(bl) == 0.0) newEmpty = true; else newLL += wk.ll.get(bl);
+      if (binCnt.get(br) == 0.0) newEmpty = true; else newLL += wk.ll.get(br);
+    } else if (prType == MOVE_DEATH) {   // old branch = the two children, new branch = their union
       int bl = tb.binA.get(cur.left.get(nd)), br = tb.binA.get(cur.right.get(nd));
+      if (binCnt.get(bl) == 0.0) oldEmpty = true; else oldLL += wk.ll.get(bl);
+      if (binCnt.get(br) == 0.0) oldEmpty = true; else oldLL += wk.ll.get(br);
       double c = binCnt.get(bl) + binCnt.get(br), s = binSum.get(bl) + binSum.get(br);
       if (c == 0.0) newEmpty = true; else newLL = leaf_loglik(c, s, sigma2, m.leafPrec);
-    } else {
-      int nn = tv_list_leaves(pt, nd, tb.list);
-      for (int i = 0; i < nn; ++i) {
-        int b = tb.binB.get(tb.list.get(i));
-        if (binCnt.get(b) == 0.0) newEmpty = true; else newLL += wk.ll.get(b);
+    } else {                             // swap / change: same leaves (DFS order) under nd before and after
+      int no = tv_list_leaves(cur, nd, tb.list);
+      for (int i = 0; i < no; ++i) {
+        int lf = tb.list.get(i);
+        int ba = tb.binA.get(lf), bb = tb.binB.get(lf);
+        if (binCnt.get(ba) == 0.0) oldEmpty = true; else oldLL += wk.ll.get(ba);
+        if (binCnt.get(bb) == 0.0) newEmpty = true; else newLL += wk.ll.get(bb);
       }
     }
     if (oldEmpty) oldLL = -10000000.0;
@@ -624,6 +641,7 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
       }
       ca.nl = nlw; ca.ni = np;
     }
+    tv_recount(cur, m, ca);
   }
   // DFS leaf list of the tree we end up with (the cache is current either way)
   const int nl = ca.nl;

@@ -33,7 +33,7 @@ class DevCpu {
     hwm_.assign((size_t)T_, 1);
     for (int t = 0; t < T_; ++t) var_[(size_t)t * nc_] = NODE_LEAF;
     cna_.assign(m, 0); cdep_.assign(m, 0); cleaf_.assign(m, 0); cpre_.assign(m, 0); cpost_.assign(m, 0);
-    cnl_.assign((size_t)T_, 0); cni_.assign((size_t)T_, 0); cvalid_.assign((size_t)T_, 0); clogpi_.assign((size_t)T_, 0.0);
+    cnl_.assign((size_t)T_, 0); cni_.assign((size_t)T_, 0); cg_.assign((size_t)T_, 0); cgn_.assign((size_t)T_, 0); cvalid_.assign((size_t)T_, 0); clogpi_.assign((size_t)T_, 0.0);
     for (int s = 0; s < 2; ++s) {
       sc_[s].pvar.assign((size_t)nc_, 0); sc_[s].pleft.assign((size_t)nc_, 0); sc_[s].pright.assign((size_t)nc_, 0); sc_[s].pparent.assign((size_t)nc_, 0);
       sc_[s].pcut.assign((size_t)nc_, 0); sc_[s].binA.assign((size_t)nc_, 0); sc_[s].binB.assign((size_t)nc_, 0); sc_[s].list.assign((size_t)nc_, 0);
@@ -52,7 +52,7 @@ class DevCpu {
     a_.var = var_.data(); a_.left = left_.data(); a_.right = right_.data(); a_.parent = parent_.data(); a_.cut = cut_.data(); a_.mu = mu_.data();
     a_.cnt = cnt_.data(); a_.hwm = hwm_.data();
     a_.cna = cna_.data(); a_.cdep = cdep_.data(); a_.cleaf = cleaf_.data(); a_.cpre = cpre_.data(); a_.cpost = cpost_.data();
-    a_.cnl = cnl_.data(); a_.cni = cni_.data(); a_.cvalid = cvalid_.data(); a_.clogpi = clogpi_.data();
+    a_.cnl = cnl_.data(); a_.cni = cni_.data(); a_.cg = cg_.data(); a_.cgn = cgn_.data(); a_.cvalid = cvalid_.data(); a_.clogpi = clogpi_.data();
     for (int s = 0; s < 2; ++s) {
       StepScratch& c = a_.sc[s];
       c.pvar = sc_[s].pvar.data(); c.pleft = sc_[s].pleft.data(); c.pright = sc_[s].pright.data(); c.pparent = sc_[s].pparent.data(); c.pcut = sc_[s].pcut.data();
@@ -289,7 +289,7 @@ class DevCpu {
   std::vector<int32_t> numCuts_, cnt_, hwm_, v_, u_;
   std::vector<double> y_, user_, X_, w_, R_, off_, offNew_, e0_, mu_, binCnt_, binSum_, lat_; bool binary_ = false;
   std::vector<int16_t> var_, left_, right_, parent_, cna_, cdep_, cleaf_, cpre_, cpost_;
-  std::vector<int32_t> cnl_, cni_, cvalid_; std::vector<double> clogpi_;
+  std::vector<int32_t> cnl_, cni_, cg_, cgn_, cvalid_; std::vector<double> clogpi_;
   Scratch sc_[2];
   std::vector<StepRecord> trace_;
   MTState rng_; ScaleState scale_; BartArrays a_;
