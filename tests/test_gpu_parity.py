@@ -169,3 +169,16 @@ def test_trees_with_more_than_128_node_slots(oracle_lib, hip_lib):
     b = run_chain(hip_lib, "s4b_", args, results_type=1)
     assert a["trace"][:, 4].max() > 128
     assert_chain_parity(a, b, stan=False)
+
+
+def test_odd_predictors_and_cut_counts(oracle_lib, hip_lib):
+    from test_host_logic import _odd_predictors_case
+    args = _odd_predictors_case()
+    assert_chain_parity(run_chain(oracle_lib, "orc_", args), run_chain(hip_lib, "s4b_", args))
+
+
+def test_node_capacity_overflow_is_reported(hip_lib):
+    args, _ = friedman_case(n=2000, T=2, warmup=10, iter=30, ranef=False, bart_args={"base": 0.99, "power": 0.25, "k": 0.3})
+    args.node_capacity = 40
+    with pytest.raises(RuntimeError, match="node_capacity|node capacity"):
+        run_chain(hip_lib, "s4b_", args, results_type=1)

@@ -148,3 +148,32 @@ def test_probit_emulated_product_matches_oracle(oracle_lib, emul_lib, ranef):
     b = run_chain(emul_lib, "emu_", args)
     assert_chain_parity(a, b)
     assert "aux.1" not in a["names"] and a["names"] == b["names"]
+
+
+def _odd_predictors_case(n=400, T=8, warmup=5, iter=15):
+    """predictors a CART sampler can trip over: a constant column, a 0/1 column, a 3-level column, a column with no
+    cut points at all (n.cuts = 0), very few cuts, many cuts, duplicated values."""
+    from stan4bart_amd import generate_friedman_data, make_sampler_args
+    d = generate_friedman_data(n, ranef=False, causal=True)
+    x = d["x"].copy()
+    xb = np.column_stack([x[:, 0], np.full(n, 3.0), d["z"], np.floor(3 * x[:, 1]), x[:, 2], np.round(x[:, 4], 1), x[:, 5], x[:, 6]])
+    n_cuts = np.array([100, 5, 1, 2, 0, 7, 1000, 3], dtype=np.int32)
+    args = make_sampler_args(d["y"], xb, X=x[:, 3:4], iter=iter, warmup=warmup, bart_args={"n.trees": T, "n.cuts": n_cuts})
+    return args
+
+
+def test_odd_predictors_and_cut_counts(oracle_lib, emul_lib):
+    args = _odd_predictors_case()
+    a = run_chain(oracle_lib, "orc_", args)
+    b = run_chain(emul_lib, "emu_", args)
+    assert_chain_parity(a, b)
+    used = np.unique(a["trace"][a["trace"][:, 2] >= 0, 2])
+    assert 4 not in used            # the predictor without cut points is never proposed
+
+
+def test_node_capacity_overflow_is_reported(emul_lib):
+    """a tree that outgrows node_capacity must surface as an error, not as silent truncation."""
+    args, _ = friedman_case(n=2000, T=2, warmup=10, iter=30, ranef=False, bart_args={"base": 0.99, "power": 0.25, "k": 0.3})
+    args.node_capacity = 40
+    with pytest.raises(RuntimeError, match="node_capacity|node capacity"):
+        run_chain(emul_lib, "emu_", args, results_type=1)
