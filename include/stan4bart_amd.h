@@ -170,6 +170,13 @@ int S4B_FN(get_stan_par_names)(s4b_sampler* s, char* buf, size_t cap);
 int S4B_FN(get_trees)(s4b_sampler* s, int64_t cap, int32_t* tree, int32_t* n_obs, int32_t* var,
                       int32_t* split, double* value, int64_t* num_nodes);
 
+/* stan4bart_predictBART(storedSampler, x_test, offset_test = NULL) — src/init.cpp:354-403, with the rescaling of
+ * R/generics.R:671-674 folded in: BART fit of every kept draw at new predictor rows, on the data scale (probit: the
+ * latent scale).  Trees are kept for the non-warmup runs of a sampler created with bart_control.keep_trees = 1
+ * (reference: keepTrees is switched on only for the sampling phase, src/init.cpp:216-221,737-744).
+ * out is n_test x num_samples (column-major); pass out = NULL to query num_samples. */
+int S4B_FN(predict_bart)(s4b_sampler* s, const double* x_test, int64_t n_test, double* out, int64_t* num_samples);
+
 /* diagnostics used by the parity tests: per-tree-update trace records of 5 int32
  * {type 0 birth 1 death 2 swap 3 change, status 1/0/-1, var, split, num_leaves} */
 int S4B_FN(set_trace)(s4b_sampler* s, int32_t enable);

@@ -28,7 +28,10 @@ thread_local std::string g_err;
 enum { OFFSET_DEFAULT = 0, OFFSET_FIXEF, OFFSET_RANEF, OFFSET_BART, OFFSET_PARAMETRIC };
 }  // namespace
 
+struct KeptSample { std::vector<int32_t> st; std::vector<double> mu; std::vector<size_t> treeStart, leafStart; double min, range; };
+
 struct s4b_sampler {
+  bool keepTrees = false; std::vector<KeptSample> kept;
   int warmup = 0, iter = 0, verbose = 0, refresh = 0;
   bool binary = false, keepFits = true;
   int offsetType = 0;
@@ -80,6 +83,7 @@ int orc_create(const s4b_bart_control* bc, const s4b_bart_data* bd, const s4b_st
     s.warmup = cc->warmup; s.iter = cc->iter; s.verbose = cc->verbose; s.refresh = cc->refresh;
     s.binary = cc->is_binary != 0; s.keepFits = cc->keep_fits != 0; s.offsetType = cc->offset_type;
     s.callback = cc->callback; s.callbackUser = cc->callback_user;
+    s.keepTrees = bc->keep_trees != 0;
     s.n = (size_t)bd->n;
     if (bd->n != sd->N) throw std::invalid_argument("bart data n != stan data N");
     if (!(cc->sigma_init > 0)) throw std::invalid_argument("sigma_init must be > 0");
@@ -185,6 +189,14 @@ int orc_run(s4b_sampler* sp, int32_t numIter, int32_t isWarmup, int32_t resultsT
           if (out->bart_test && nTest) std::memcpy(out->bart_test + slot * nTest, res.test.data(), nTest * sizeof(double));
           if (out->bart_varcount) for (size_t j = 0; j < p; ++j) out->bart_varcount[slot * p + j] = (int32_t)res.varcount[j];
         }
+        if (s.keepTrees && !isWarmup) {
+          KeptSample ks; ks.min = s.bart->scaleMin; ks.range = s.bart->scaleRange;
+          for (int t = 0; t < s.bart->cfg.numTrees; ++t) {
+            ks.treeStart.push_back(ks.st.size() / 2); ks.leafStart.push_back(ks.mu.size());
+            s.bart->serializeTree(t, ks.st, ks.mu);
+          }
+          s.kept.push_back(std::move(ks));
+        }
         if (s.callback) s.callback(s.callbackUser, res.train.data(), nTest ? res.test.data() : nullptr, s.row.data(), numPars);
       }
       if (s.keepFits) ++slot;
@@ -280,6 +292,37 @@ int orc_get_leaf_assignment(s4b_sampler* s, int32_t t, int32_t* out) {
 int orc_get_counters(s4b_sampler* s, int64_t out[3]) { out[0] = s->model->gradEvals; out[1] = s->treeUpdates; out[2] = 0; return 0; }
 
 int orc_profile_sweep(s4b_sampler*, int32_t, double out[8]) { for (int i = 0; i < 8; ++i) out[i] = 0.0; return 0; }
+int orc_predict_bart(s4b_sampler* s, const double* x_test, int64_t n_test, double* out, int64_t* num_samples) {
+  *num_samples = (int64_t)s->kept.size();
+  if (!out) return 0;
+  const BartFit& f = *s->bart;
+  std::vector<uint16_t> xb((size_t)f.p * (size_t)n_test);
+  for (size_t j = 0; j < f.p; ++j) for (int64_t i = 0; i < n_test; ++i) {
+    int c = 0; while (c < f.numCuts[j] && x_test[j * (size_t)n_test + i] > f.cuts[j][(size_t)c]) ++c;
+    xb[j * (size_t)n_test + i] = (uint16_t)c;
+  }
+  for (size_t k = 0; k < s->kept.size(); ++k) {
+    const KeptSample& ks = s->kept[k];
+    for (int64_t i = 0; i < n_test; ++i) {
+      double fit = 0.0;
+      size_t pos = 0, leaf = 0;
+      for (int t = 0; t < f.cfg.numTrees; ++t) {
+        // walk the preorder serialisation of tree t: (var, split) pairs, leaves as (-1, count)
+        size_t start = ks.treeStart[(size_t)t], lstart = ks.leafStart[(size_t)t];
+        pos = start; leaf = lstart;
+        // descend: at an internal node go to the left child (next entry) or skip the left subtree
+        while (ks.st[2 * pos] >= 0) {
+          bool right = (int)xb[(size_t)ks.st[2 * pos] * (size_t)n_test + i] > ks.st[2 * pos + 1];
+          ++pos;
+          if (right) { int depth = 1; while (depth > 0) { if (ks.st[2 * pos] >= 0) ++depth; else { --depth; ++leaf; } ++pos; } }
+        }
+        fit += ks.mu[leaf];
+      }
+      out[(size_t)k * (size_t)n_test + i] = s->binary ? fit : (fit + 0.5) * ks.range + ks.min;
+    }
+  }
+  return 0;
+}
 void orc_free(s4b_sampler* s) { delete s; }
 
 // ---- small extras used only by tests: direct access to the RNG restatements and the model ----

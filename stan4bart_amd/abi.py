@@ -243,7 +243,7 @@ class Sampler:
     def _bind(self):
         for name in ("create", "run", "disengage_adaptation", "print_initial_summary", "get_parametric_mean",
                      "get_bart_data_range", "get_r_rng_state", "set_r_rng_state", "get_dims", "get_stan_par_names",
-                     "get_trees", "set_trace", "get_trace", "get_leaf_assignment", "get_counters", "profile_sweep"):
+                     "get_trees", "set_trace", "get_trace", "get_leaf_assignment", "get_counters", "profile_sweep", "predict_bart"):
             getattr(self._lib, self._pfx + name).restype = C.c_int
         getattr(self._lib, self._pfx + "last_error").restype = C.c_char_p
         getattr(self._lib, self._pfx + "free").restype = None
@@ -343,6 +343,16 @@ class Sampler:
         out = (C.c_int64 * 3)()
         self._check(self._f("get_counters")(self._h, out))
         return np.array(list(out), dtype=np.int64)
+
+    def predict_bart(self, x_test: np.ndarray) -> np.ndarray:
+        """``stan4bart_predictBART``: BART fit of every kept draw (keep_trees) at new rows, [n_test x samples]."""
+        xt = _f64(x_test)
+        ns = C.c_int64()
+        self._check(self._f("predict_bart")(self._h, _dp(xt), xt.shape[0], None, C.byref(ns)))
+        out = np.zeros((xt.shape[0], ns.value), order="F")
+        if ns.value:
+            self._check(self._f("predict_bart")(self._h, _dp(xt), xt.shape[0], _dp(out), C.byref(ns)))
+        return out
 
     def profile_sweep(self, n_sweeps: int = 1) -> dict:
         """Extra BART sweeps timed with HIP events on the sampler's stream (measurement hook of the HIP library)."""

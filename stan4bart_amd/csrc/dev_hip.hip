@@ -797,6 +797,24 @@ __global__ __launch_bounds__(BLOCK) void k_test_fits(BartArrays a, double* out) 
   }
 }
 
+// stored-tree prediction (stan4bart_predictBART): one thread per (test row, kept draw)
+__global__ __launch_bounds__(BLOCK) void k_predict(const uint16_t* xb, int64_t nT, const PackedNode* nodes, const int64_t* treeStart, int64_t S, int T,
+                                                   const double* scale, int binary, double* out) {
+  const int64_t total = nT * S;
+  for (int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * BLOCK) {
+    const int64_t k = idx / nT, i = idx - k * nT;
+    double f = 0.0;
+    for (int t = 0; t < T; ++t) {
+      const PackedNode* base = nodes + treeStart[k * T + t];
+      int nd = 0;
+      PackedNode p = base[0];
+      while (p.var >= 0) { nd = (xb[(size_t)p.var * (size_t)nT + i] <= p.cut) ? p.left : p.right; p = base[nd]; }
+      f += p.mu;
+    }
+    out[idx] = binary ? f : (f + 0.5) * scale[2 * k + 1] + scale[2 * k];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 class DevHip {
  public:
@@ -1087,6 +1105,22 @@ class DevHip {
     int g = (int)std::min<int64_t>(GRID_MAX, std::max<int64_t>(1, (nTest_ + BLOCK - 1) / BLOCK));
     hipLaunchKernelGGL(k_test_fits, dim3(g), dim3(BLOCK), 0, stream_, a_, testOut_); ++launches_;
     download(out, testOut_, (size_t)nTest_); sync();
+  }
+
+  void predict_stored(const uint16_t* xb, int64_t nT, const PackedNode* nodes, size_t numNodes, const int64_t* treeStart, int64_t S, int T,
+                      const double* scale, int binary, double* out) {
+    uint16_t* dx = nullptr; PackedNode* dn = nullptr; int64_t* dt = nullptr; double* ds = nullptr; double* dout = nullptr;
+    auto freeAll = [&] { (void)hipFree(dx); (void)hipFree(dn); (void)hipFree(dt); (void)hipFree(ds); (void)hipFree(dout); };
+    try {
+      HIP_OK(hipMalloc(&dx, (size_t)a_.P * (size_t)nT * 2)); HIP_OK(hipMalloc(&dn, std::max<size_t>(16, numNodes * sizeof(PackedNode))));
+      HIP_OK(hipMalloc(&dt, (size_t)S * T * 8)); HIP_OK(hipMalloc(&ds, (size_t)S * 16)); HIP_OK(hipMalloc(&dout, (size_t)S * (size_t)nT * 8));
+      upload(dx, xb, (size_t)a_.P * (size_t)nT); upload(dn, nodes, numNodes); upload(dt, treeStart, (size_t)S * T); upload(ds, scale, (size_t)S * 2);
+      const int64_t total = nT * S;
+      const int g = (int)std::min<int64_t>(4096, std::max<int64_t>(1, (total + BLOCK - 1) / BLOCK));
+      hipLaunchKernelGGL(k_predict, dim3(g), dim3(BLOCK), 0, stream_, dx, nT, dn, dt, S, T, ds, binary, dout); ++launches_;
+      download(out, dout, (size_t)total); sync();
+    } catch (...) { freeAll(); throw; }
+    freeAll();
   }
 
   // ---- Stan inputs

@@ -29,6 +29,9 @@ namespace s4b {
 
 enum { OFFSET_DEFAULT = 0, OFFSET_FIXEF, OFFSET_RANEF, OFFSET_BART, OFFSET_PARAMETRIC };
 
+// a node of a kept tree (predict): children are slot ids relative to the tree's first record
+struct PackedNode { int16_t var; uint16_t cut; int16_t left, right; double mu; };
+
 // everything the device layer needs at creation (host pointers, valid during init() only)
 struct DevInit {
   int64_t n = 0, nTest = 0; int32_t P = 0, T = 0, nc = 256, device = 0;
@@ -63,6 +66,7 @@ class SamplerCore {
     warmup_ = cc->warmup; verbose_ = cc->verbose; keepFits_ = cc->keep_fits != 0; offsetType_ = cc->offset_type;
     callback_ = cc->callback; callbackUser_ = cc->callback_user;
     thin_ = bc->n_thin > 0 ? bc->n_thin : 1;
+    keepTrees_ = bc->keep_trees != 0;
     nc_ = bc->node_capacity > 0 ? bc->node_capacity : 256;
     if (nc_ < 3 || nc_ > 32000) throw std::invalid_argument("node_capacity must be in [3, 32000]");
     if (cc->offset) { userOffset_.assign(cc->offset, cc->offset + n_); hasUserOffset_ = true; }
@@ -209,6 +213,7 @@ class SamplerCore {
           if (out->bart_test && nTest_) std::memcpy(out->bart_test + slot * nTest_, test.data(), nTest_ * sizeof(double));
           if (out->bart_varcount) var_counts(out->bart_varcount + slot * (size_t)P_);
         }
+        if (keepTrees_ && !isWarmup) keep_current_trees();
         if (callback_) callback_(callbackUser_, train.data(), nTest_ ? test.data() : nullptr, row_.data(), numPars);
         if (timing) tph[3] += now() - t0;
       }
@@ -265,6 +270,17 @@ class SamplerCore {
     }
     return cnt;
   }
+  // stan4bart_predictBART over the trees kept while sampling (reference src/init.cpp:354-403)
+  int64_t predict(const double* xTest, int64_t nT, double* out) {
+    const int64_t S = (int64_t)keptScale_.size() / 2;
+    if (!out) return S;
+    if (nT < 1 || !xTest) throw std::invalid_argument("predict: x_test must have at least one row");
+    if (S == 0) return 0;
+    std::vector<uint16_t> xb((size_t)P_ * (size_t)nT);
+    bin_matrix(xTest, (size_t)nT, xb);
+    dev_.predict_stored(xb.data(), nT, keptNodes_.data(), keptNodes_.size(), keptTreeStart_.data(), S, T_, keptScale_.data(), binary_ ? 1 : 0, out);
+    return S;
+  }
   void set_trace(bool on) { dev_.set_trace(on); }
   int64_t get_trace(int64_t cap, int32_t* out) { return dev_.get_trace(cap, out); }
   void leaf_assignment(int t, int32_t* out) {
@@ -290,6 +306,20 @@ class SamplerCore {
     void alloc(int T, int nc) { size_t m = (size_t)T * nc; na.assign((size_t)nc, 0); dep.assign((size_t)nc, 0); var.assign(m, NODE_FREE); left.assign(m, -1); right.assign(m, -1); parent.assign(m, -1);
                                 cut.assign(m, 0); mu.assign(m, 0.0); cnt.assign(m, 0); hwm.assign((size_t)T, 1); }
   };
+  // one kept draw = the used node slots of every tree, packed as 16-byte records
+  void keep_current_trees() {
+    HostTrees h; download_trees(h);
+    for (int t = 0; t < T_; ++t) {
+      keptTreeStart_.push_back((int64_t)keptNodes_.size());
+      const size_t o = (size_t)t * nc_;
+      for (int i = 0; i < h.hwm[(size_t)t]; ++i) {
+        PackedNode pn; pn.var = h.var[o + i]; pn.cut = h.cut[o + i]; pn.left = h.left[o + i]; pn.right = h.right[o + i]; pn.mu = h.mu[o + i];
+        keptNodes_.push_back(pn);
+      }
+    }
+    ScaleState sc; dev_.get_scale(sc);
+    keptScale_.push_back(sc.min); keptScale_.push_back(sc.range);
+  }
   void download_trees(HostTrees& h) { h.alloc(T_, nc_); dev_.download_trees(h.var.data(), h.cut.data(), h.left.data(), h.right.data(), h.parent.data(), h.mu.data(), h.cnt.data(), h.hwm.data()); }
 
   int stan_mode() const {   // how the Stan offset is formed from the BART fit (reference src/init.cpp:831-839)
@@ -414,6 +444,8 @@ class SamplerCore {
   std::vector<double> pgDepth_, logPg_, log1mPg_, logInt_;
   ModelView hostModelView_;
   std::unique_ptr<HostModel> model_; std::unique_ptr<Nuts> nuts_;
+  bool keepTrees_ = false;
+  std::vector<PackedNode> keptNodes_; std::vector<int64_t> keptTreeStart_; std::vector<double> keptScale_;
   std::vector<double> row_, cX_, cZ_, gram_; std::vector<int> gramPtr_, gramCol_; double s0_ = 0, sigma_ = 1;
   long treeUpdates_ = 0;
 };

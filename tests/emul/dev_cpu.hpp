@@ -192,6 +192,19 @@ class DevCpu {
       R_[i] = lat_[i] - F;
     }
   }
+  void predict_stored(const uint16_t* xb, int64_t nT, const PackedNode* nodes, size_t, const int64_t* treeStart, int64_t S, int T, const double* scale,
+                      int binary, double* out) {
+    for (int64_t k = 0; k < S; ++k) for (int64_t i = 0; i < nT; ++i) {
+      double f = 0.0;
+      for (int t = 0; t < T; ++t) {
+        const PackedNode* base = nodes + treeStart[k * T + t];
+        int nd = 0;
+        while (base[nd].var >= 0) nd = (xb[(size_t)base[nd].var * (size_t)nT + i] <= base[nd].cut) ? base[nd].left : base[nd].right;
+        f += base[nd].mu;
+      }
+      out[(size_t)k * (size_t)nT + i] = binary ? f : (f + 0.5) * scale[2 * k + 1] + scale[2 * k];
+    }
+  }
   void profile_sweep(int nSweeps, int thin, double* out) { for (int i = 0; i < 8; ++i) out[i] = 0.0; for (int k = 0; k < nSweeps; ++k) sweep(thin); }
   void test_fits(double* out) {
     for (size_t i = 0; i < nTest_; ++i) {

@@ -182,3 +182,27 @@ def test_node_capacity_overflow_is_reported(hip_lib):
     args.node_capacity = 40
     with pytest.raises(RuntimeError, match="node_capacity|node capacity"):
         run_chain(hip_lib, "s4b_", args, results_type=1)
+
+
+@pytest.mark.parametrize("family", ["gaussian", "binomial"])
+def test_predict_equals_extract(hip_lib, family):
+    """keepTrees + predict on the device (reference test-01-continuous.R:204-246): predictions at the training / test rows
+    equal the stored fits of the same draws."""
+    from stan4bart_amd import GroupTerm, RRng, generate_friedman_data, make_sampler_args
+    from stan4bart_amd.abi import Sampler
+    d = generate_friedman_data(3000, ranef=True, causal=True, binary=family == "binomial")
+    x = d["x"]
+    xb = x[:, [0, 1, 2, 4, 5, 6, 7, 8, 9]]
+    xt = xb[:50] + 0.01
+    args = make_sampler_args(d["y"], xb, X=np.column_stack([x[:, 3], d["z"]]), groups=[GroupTerm(d["g1"]), GroupTerm(d["g2"])],
+                             family=family, iter=13, warmup=7, x_test=xt, bart_args={"n.trees": 25, "keepTrees": True})
+    rng = RRng(4242)
+    args.seed = int(rng.sample_int(2147483647, 1)[0])
+    s = Sampler(hip_lib, "s4b_", args, rng.state)
+    s.run(7, True)
+    s.disengage_adaptation()
+    r = s.run(6, False)
+    ptrain, ptest = s.predict_bart(xb), s.predict_bart(xt)
+    s.free()
+    np.testing.assert_allclose(ptrain, r["bart"]["train"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(ptest, r["bart"]["test"], rtol=1e-9, atol=1e-9)

@@ -107,7 +107,7 @@ def _declared_symbols():
 def test_product_library_exports_every_declared_symbol(hip_lib):
     """the C-ABI library loads on a CPU-only box and exports exactly what include/stan4bart_amd.h declares."""
     names = _declared_symbols()
-    assert len(names) == 18
+    assert len(names) == 19
     for n in names:
         assert hasattr(hip_lib, "s4b_" + n), n
     out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "stan4bart_amd", "csrc", "libs4b.so")],
@@ -177,3 +177,33 @@ def test_node_capacity_overflow_is_reported(emul_lib):
     args.node_capacity = 40
     with pytest.raises(RuntimeError, match="node_capacity|node capacity"):
         run_chain(emul_lib, "emu_", args, results_type=1)
+
+
+@pytest.mark.parametrize("family", ["gaussian", "binomial"])
+def test_predict_equals_extract(oracle_lib, emul_lib, family):
+    """reference tests/testthat/test-01-continuous.R:204-246 / test-02-binary.R:81-123: with keepTrees, predicting at the
+    training rows reproduces the stored training fits, and at the test rows the stored test fits; oracle and product agree."""
+    from stan4bart_amd import GroupTerm, RRng, generate_friedman_data, make_sampler_args
+    from stan4bart_amd.abi import Sampler
+    d = generate_friedman_data(150, ranef=True, causal=True, binary=family == "binomial")
+    x = d["x"]
+    xb = x[:, [0, 1, 2, 4, 5, 6, 7, 8, 9]]
+    xt = xb[:20] + 0.01
+    res = {}
+    for key, lib, pfx in (("o", oracle_lib, "orc_"), ("e", emul_lib, "emu_")):
+        args = make_sampler_args(d["y"], xb, X=np.column_stack([x[:, 3], d["z"]]), groups=[GroupTerm(d["g1"]), GroupTerm(d["g2"])],
+                                 family=family, iter=13, warmup=7, x_test=xt, bart_args={"n.trees": 11, "keepTrees": True})
+        rng = RRng(4242)
+        args.seed = int(rng.sample_int(2147483647, 1)[0])
+        s = Sampler(lib, pfx, args, rng.state)
+        s.run(7, True)
+        s.disengage_adaptation()
+        r = s.run(6, False)
+        ptrain, ptest = s.predict_bart(xb), s.predict_bart(xt)
+        s.free()
+        assert ptrain.shape == (150, 6) and ptest.shape == (20, 6)
+        np.testing.assert_allclose(ptrain, r["bart"]["train"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(ptest, r["bart"]["test"], rtol=1e-9, atol=1e-9)
+        res[key] = (ptrain, ptest)
+    np.testing.assert_allclose(res["o"][0], res["e"][0], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(res["o"][1], res["e"][1], rtol=1e-6, atol=1e-9)
