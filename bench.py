@@ -43,6 +43,38 @@ def build_case(n, p, trees, device, warmup, steps):
     return args
 
 
+def target_roofline_leg(lib, n, p, trees, device, sweeps):
+    """north_star's roofline target is quoted at n = 1e7, p = 50, ntree = 200 (larger than the metric's workload): measure
+    the same dominant kernel there too, live, on a BART-sized case (Friedman surface, fixed effects X4 + z, numpy's
+    generator for the 5e8 uniforms — the R-compatible stream would take minutes on the host and the sweep's cost does
+    not depend on which generator made x)."""
+    from stan4bart_amd import RRng, make_sampler_args
+    from stan4bart_amd.abi import Sampler
+    g = np.random.default_rng(99)
+    x = np.empty((n, p), order="F")
+    for j in range(p):
+        x[:, j] = g.random(n)
+    z = (g.random(n) < 0.2).astype(np.float64)
+    y = (10.0 * np.sin(np.pi * x[:, 0] * x[:, 1]) + 20.0 * (x[:, 2] - 0.5) ** 2 + 5.0 * x[:, 4] + 10.0 * x[:, 3] + 5.0 * z
+         + g.standard_normal(n))
+    X = np.column_stack([x[:, 3], z])
+    xb = np.asfortranarray(np.delete(x, 3, axis=1))
+    del x
+    args = make_sampler_args(y, xb, X=X, groups=[], iter=8, warmup=4, keep_fits=False, bart_args={"n.trees": trees},
+                             device=device)
+    rng = RRng(4321)
+    args.seed = int(rng.sample_int(2147483647, 1)[0])
+    s = Sampler(lib, "s4b_", args, rng.state)
+    s.run(2, True, 0)
+    prof = s.profile_sweep(sweeps)
+    s.free()
+    achieved = 22.0 * n / (prof["stats_us"] * 1e-6) / 1e9
+    return {"workload": f"Friedman n={n}, p={p}, ntree={trees} (north_star roofline target config)", "kernel": "k_tree",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "avg_launch_us": prof["stats_us"], "k_control_us": prof["control_us"], "algorithmic_bytes_per_launch": 22.0 * n,
+            "sweep_wall_us": prof["sweep_wall_us"]}
+
+
 def cpu_baseline(n, p, trees, iters):
     """Time the CPU oracle (single thread, the reference's execution model: R/stan4bart_fit.R:437-439) on the
     same workload for a bounded number of Gibbs iterations."""
@@ -76,6 +108,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-sweeps", type=int, default=2)
+    ap.add_argument("--target-n", type=int, default=10_000_000,
+                    help="also measure the sweep kernel at north_star's roofline-target size (0 = skip; N = 1 only)")
     a = ap.parse_args()
 
     import torch
@@ -122,6 +156,10 @@ def main():
 
     prof = sampler.profile_sweep(a.profile_sweeps) if rank == 0 else None
     sampler.free()
+    del args
+    target = None
+    if world == 1 and a.target_n > 0 and a.target_n != a.n:
+        target = target_roofline_leg(lib, a.target_n, a.p, a.trees, local_rank, a.profile_sweeps)
 
     if rank == 0:
         n = a.n
@@ -156,6 +194,13 @@ def main():
                                          "achieved_GBs_incl_control": 22.0 * n / (tree_update_us * 1e-6) / 1e9},
                          "sweep_wall_us": prof["sweep_wall_us"]},
         }
+        if target is not None:
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    target["traffic"] = json.load(f).get(str(a.target_n), {}).get("bytes_per_launch")
+            except (OSError, ValueError):
+                target["traffic"] = None
+            rec["roofline_target_config"] = target
         if world == 1 and not a.no_cpu_baseline:
             v, secs = cpu_baseline(a.n, a.p, a.trees, a.cpu_iters)
             rec["cpu_baseline"] = {"value": v, "unit": "Gibbs iterations/s/chain", "cores": 1, "kind": "port",
