@@ -24,6 +24,10 @@ def build_library(force: bool = False) -> str:
 def load_library() -> ctypes.CDLL:
     global _lib
     if _lib is None:
+        path = os.environ.get("S4B_LIB_PATH", LIB_PATH)   # tuning builds of the same HIP sources (e.g. `make timing`)
+        if path != LIB_PATH:
+            _lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            return _lib
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `make -C stan4bart_amd/csrc` "

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
   __shared__ double s_red[2][BLOCK / 64][64];
   __shared__ Proposal s_prT, s_prN;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  S4B_TICK(tk0);
   const bool doDecide = t >= 0, doPropose = next >= 0;
   const int tt = doDecide ? t : 0, tn = doPropose ? next : 0;
   const StepScratch& cT = a.sc[tt & 1];
@@ -361,25 +362,51 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
   curN.parent.r = a.parent[oN + li]; curN.na.r = a.cna[oN + li]; curN.dep.r = a.cdep[oN + li]; curN.nc = curT.nc;
   caN.leaf.r = a.cleaf[oN + li]; caN.pre.r = a.cpre[oN + li]; caN.post.r = a.cpost[oN + li];
   caN.nl = cnlN; caN.ni = cniN; caN.g = a.cg[tn]; caN.gn = a.cgn[tn]; caN.logPi = clogpiN; caN.valid = cvalidN;
-  // partials of the first 8 bins (whether or not the proposal has that many: the grid-sized slabs exist)
+  // partials of the first 8 bins (whether or not the proposal has that many: the grid-sized slabs exist) and the small
+  // shared state, all fetched in this same hop: fixed-trip, predicated loads first, uses afterwards
   double ps[8], pc[8];
+  {
+    const int b0 = threadIdx.x, b1 = threadIdx.x + BLOCK;
+    const bool in0 = doDecide && b0 < a.grid, in1 = doDecide && b1 < a.grid;
+    double qs[8], qc[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { ps[j] = 0.0; pc[j] = 0.0; }
-  if (doDecide) {
-    for (int b = threadIdx.x; b < a.grid; b += BLOCK) {
+    for (int j = 0; j < 8; ++j) {
+      ps[j] = in0 ? a.partSum[(size_t)j * a.grid + b0] : 0.0; pc[j] = in0 ? a.partCnt[(size_t)j * a.grid + b0] : 0.0;
+      qs[j] = in1 ? a.partSum[(size_t)j * a.grid + b1] : 0.0; qc[j] = in1 ? a.partCnt[(size_t)j * a.grid + b1] : 0.0;
+    }
+    constexpr int MTW = (int)(sizeof(MTState) / 4), MTJ = (MTW + BLOCK - 1) / BLOCK;
+    uint32_t mtw[MTJ];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { ps[j] += a.partSum[(size_t)j * a.grid + b]; pc[j] += a.partCnt[(size_t)j * a.grid + b]; }
+    for (int j = 0; j < MTJ; ++j) { const int i = threadIdx.x + j * BLOCK; mtw[j] = i < MTW ? ((const uint32_t*)a.rng)[i] : 0u; }
+    int32_t* numCuts = (int32_t*)smem;
+    double* logInt = (double*)(smem + ((size_t)a.P * 4 + 15) / 16 * 16);
+    const int i0 = threadIdx.x;
+    const int32_t nc0 = i0 < a.P ? a.numCuts[i0] : 0;
+    const double li0 = i0 < a.model.logIntLen ? a.model.logInt[i0] : 0.0;
+    double tb0 = 0.0, tb1 = 0.0, tb2 = 0.0;
+    if (i0 < S4B_MAX_DEPTH) { tb0 = a.model.pgDepth[i0]; tb1 = a.model.logPg[i0]; tb2 = a.model.log1mPg[i0]; }
+    // ---- uses
+#pragma unroll
+    for (int j = 0; j < MTJ; ++j) { const int i = threadIdx.x + j * BLOCK; if (i < MTW) ((uint32_t*)&s_rng)[i] = mtw[j]; }
+    if (i0 < a.P) numCuts[i0] = nc0;
+    if (i0 < a.model.logIntLen) logInt[i0] = li0;
+    if (i0 < S4B_MAX_DEPTH) { s_tab[i0] = tb0; s_tab[S4B_MAX_DEPTH + i0] = tb1; s_tab[2 * S4B_MAX_DEPTH + i0] = tb2; }
+    for (int i = threadIdx.x + BLOCK; i < a.P; i += BLOCK) numCuts[i] = a.numCuts[i];
+    for (int i = threadIdx.x + BLOCK; i < a.model.logIntLen; i += BLOCK) logInt[i] = a.model.logInt[i];
+    for (int i = threadIdx.x + BLOCK; i < S4B_MAX_DEPTH; i += BLOCK) {
+      s_tab[i] = a.model.pgDepth[i]; s_tab[S4B_MAX_DEPTH + i] = a.model.logPg[i]; s_tab[2 * S4B_MAX_DEPTH + i] = a.model.log1mPg[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ps[j] += qs[j]; pc[j] += qc[j]; }
+    if (doDecide) {
+      for (int b = threadIdx.x + 2 * BLOCK; b < a.grid; b += BLOCK) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ps[j] += a.partSum[(size_t)j * a.grid + b]; pc[j] += a.partCnt[(size_t)j * a.grid + b]; }
+      }
     }
   }
-  // small shared state -> LDS
   int32_t* numCuts = (int32_t*)smem;
   double* logInt = (double*)(smem + ((size_t)a.P * 4 + 15) / 16 * 16);
-  for (int i = threadIdx.x; i < (int)(sizeof(MTState) / 4); i += BLOCK) ((uint32_t*)&s_rng)[i] = ((const uint32_t*)a.rng)[i];
-  for (int i = threadIdx.x; i < a.P; i += BLOCK) numCuts[i] = a.numCuts[i];
-  for (int i = threadIdx.x; i < a.model.logIntLen; i += BLOCK) logInt[i] = a.model.logInt[i];
-  for (int i = threadIdx.x; i < S4B_MAX_DEPTH; i += BLOCK) {
-    s_tab[i] = a.model.pgDepth[i]; s_tab[S4B_MAX_DEPTH + i] = a.model.logPg[i]; s_tab[2 * S4B_MAX_DEPTH + i] = a.model.log1mPg[i];
-  }
 
   // ---- path selection (uniform over the workgroup) -----------------------------------------------------
   int need = 0, nb = 0;
@@ -416,6 +443,8 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
   }
   __syncthreads();
   if (wv != 0) return;
+  S4B_TICK(tk1);
+  s_rng.pad = 1;   // one whole wave owns the generator from here on: lane-parallel block regeneration
 
   // ---- wave 0: wave-uniform control code on register-resident arrays -------------------------------------
   ModelView m = a.model;
@@ -442,6 +471,7 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
       if (a.traceOn) push_trace(a, rec);
     }
   }
+  S4B_TICK(tk2);
   if (doPropose) {
     if (!caN.valid) {   // the tree changed since its lists were built: rebuild memo + lists + log prior, keep them
       tv_rebuild_cache(curN, m, caN);
@@ -458,8 +488,15 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
                          cN.pna[lane] = (int16_t)tbN.prop.na.r; cN.pdep[lane] = (int16_t)tbN.prop.dep.r; }
     if (lane == 0) *cN.prop = s_prN;
   }
+  S4B_TICK(tk3);
   // ---- RNG state back to global
+  s_rng.pad = 0;
   for (int i = lane; i < (int)(sizeof(MTState) / 4); i += 64) ((uint32_t*)a.rng)[i] = ((const uint32_t*)&s_rng)[i];
+#ifdef S4B_CONTROL_TIMING
+  { S4B_TICK(tk4);
+    if (lane == 0 && doDecide && doPropose) { atomicAdd((unsigned long long*)&g_dbg[0], (unsigned long long)(tk1 - tk0)); atomicAdd((unsigned long long*)&g_dbg[1], (unsigned long long)(tk2 - tk1));
+      atomicAdd((unsigned long long*)&g_dbg[2], (unsigned long long)(tk3 - tk2)); atomicAdd((unsigned long long*)&g_dbg[3], (unsigned long long)(tk4 - tk3)); atomicAdd((unsigned long long*)&g_dbg[4], 1ull); } }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

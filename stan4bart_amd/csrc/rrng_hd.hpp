@@ -36,10 +36,39 @@ namespace s4b {
 struct MTState {
   uint32_t mt[624];
   int32_t mti;
-  int32_t pad;
+  int32_t pad;   // device only: 1 while a full wave owns the state (lane-parallel block regeneration), else 0
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The block recurrence mt[k] <- mt[k+397 mod 624] ^ f(mt[k], mt[k+1 mod 624]) only reaches back 227 positions
+// for its updated inputs, so 64 consecutive elements can be produced at once (reads of a chunk happen before
+// its writes: one wave, lockstep).  Same values as the sequential loop.
+__device__ inline void mt_regenerate_wave(MTState* s) {
+  uint32_t* mt = s->mt;
+  const int lane = (int)(threadIdx.x & 63);
+  for (int base = 0; base < 624; base += 64) {
+    const int k = base + lane;
+    const bool in = k < 624;
+    const int k1 = (k + 1 >= 624) ? k + 1 - 624 : k + 1, k397 = (k + 397 >= 624) ? k + 397 - 624 : k + 397;
+    uint32_t a = in ? mt[k] : 0u, b = in ? mt[k1] : 0u, c = in ? mt[k397] : 0u;
+    uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    uint32_t v = c ^ (y >> 1);
+    if (y & 1u) v ^= 0x9908b0dfu;
+    if (in) mt[k] = v;
+    // the next chunk reads what other lanes have just written: order the LDS traffic wave-wide (the compiler
+    // would otherwise be free to hoist the next chunk's loads, which never alias this lane's own store)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  s->mti = 0;
+}
+#endif
+
 S4B_HD inline void mt_regenerate(MTState* s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (S4B_UNI(s->pad) == 1) { mt_regenerate_wave(s); return; }
+#endif
   uint32_t* mt = s->mt;
   for (int k = 0; k < 624; ++k) {
     uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);

@@ -70,7 +70,7 @@ class SamplerCore {
     nc_ = bc->node_capacity > 0 ? bc->node_capacity : 256;
     if (nc_ < 3 || nc_ > 32000) throw std::invalid_argument("node_capacity must be in [3, 32000]");
     if (cc->offset) { userOffset_.assign(cc->offset, cc->offset + n_); hasUserOffset_ = true; }
-    rng_.mti = (int32_t)rstate[0];
+    rng_.mti = (int32_t)rstate[0]; rng_.pad = 0;
     std::memcpy(rng_.mt, rstate + 1, 624 * sizeof(uint32_t));
 
     // ---- Stan spec + host copies of the design (the reference copies them too: stan_sampler.cpp:197-249)
@@ -232,7 +232,7 @@ class SamplerCore {
   }
   void data_range(double out[2]) { ScaleState s; dev_.get_scale(s); out[0] = s.min; out[1] = s.max; }
   void get_rng(uint32_t* st) { dev_.download_rng(rng_); st[0] = (uint32_t)rng_.mti; std::memcpy(st + 1, rng_.mt, 624 * 4); }
-  void set_rng(const uint32_t* st) { rng_.mti = (int32_t)st[0]; std::memcpy(rng_.mt, st + 1, 624 * 4); dev_.upload_rng(rng_); }
+  void set_rng(const uint32_t* st) { rng_.mti = (int32_t)st[0]; rng_.pad = 0; std::memcpy(rng_.mt, st + 1, 624 * 4); dev_.upload_rng(rng_); }
   void dims(int64_t d[5]) { d[0] = (int64_t)row_.size(); d[1] = (int64_t)n_; d[2] = (int64_t)nTest_; d[3] = P_; d[4] = T_; }
   std::string par_names() const {
     const StanSpec& m = model_->sp;

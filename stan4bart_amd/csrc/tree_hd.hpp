@@ -160,8 +160,18 @@ template <class TR> S4B_HD inline int tv_num_avail_compute(const TR& t, const Mo
 }
 
 // memoised per-node info: fill once per (tree, step); afterwards tv_num_avail / tv_depth_of are O(1)
+// Top-down: going from the parent to n only the parent's own predictor v can become exhausted (its interval
+// loses the side of the cut n is not on); everything else is inherited.  Requires the parent's memo (the
+// callers fill in pre-order).  Equals tv_num_avail_compute / tv_depth, which remain as the definition.
 template <class TR> S4B_HD inline void tv_fill_info_node(TR& t, const ModelView& m, int n) {
-  t.na.set(n, (int16_t)tv_num_avail_compute(t, m, n)); t.dep.set(n, (int16_t)tv_depth(t, n));
+  const int par = t.parent.get(n);
+  if (par < 0) { t.na.set(n, (int16_t)m.Pvalid); t.dep.set(n, 0); return; }
+  const int v = t.var.get(par), s = (int)t.cut.get(par);
+  int lo, hi; tv_interval(t, m, par, v, lo, hi);
+  const bool isLeft = n == t.left.get(par);
+  const int loN = isLeft ? lo : (s + 1 > lo ? s + 1 : lo), hiN = isLeft ? (s - 1 < hi ? s - 1 : hi) : hi;
+  const int gone = (lo <= hi && loN > hiN) ? 1 : 0;
+  t.na.set(n, (int16_t)((int)t.na.get(par) - gone)); t.dep.set(n, (int16_t)((int)t.dep.get(par) + 1));
 }
 template <class TR> S4B_HD inline void tv_fill_info(TR& t, const ModelView& m, int root) {
   int nd, k; Walker<TR> w(t, root);
