@@ -413,6 +413,7 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
   if (doDecide) { need = prT.hwm > hwmT ? prT.hwm : hwmT; nb = prT.nbA + prT.nbB; }
   if (doPropose && hwmN + 2 > need) need = hwmN + 2;
   const bool wavePath = need <= 64 && nb <= 64 && need <= nc + 2;
+  S4B_TICK(tkA);
   if (!wavePath) {   // large tree: sequential code straight on the global arrays
     if (doDecide) {
       for (int k = wv; k < nb; k += BLOCK / 64) {
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
     }
     if (threadIdx.x == 0) s_prT = prT;
   }
+  S4B_TICK(tkB);
   __syncthreads();
   if (wv != 0) return;
   S4B_TICK(tk1);
@@ -495,7 +497,8 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
 #ifdef S4B_CONTROL_TIMING
   { S4B_TICK(tk4);
     if (lane == 0 && doDecide && doPropose) { atomicAdd((unsigned long long*)&g_dbg[0], (unsigned long long)(tk1 - tk0)); atomicAdd((unsigned long long*)&g_dbg[1], (unsigned long long)(tk2 - tk1));
-      atomicAdd((unsigned long long*)&g_dbg[2], (unsigned long long)(tk3 - tk2)); atomicAdd((unsigned long long*)&g_dbg[3], (unsigned long long)(tk4 - tk3)); atomicAdd((unsigned long long*)&g_dbg[4], 1ull); } }
+      atomicAdd((unsigned long long*)&g_dbg[2], (unsigned long long)(tk3 - tk2)); atomicAdd((unsigned long long*)&g_dbg[3], (unsigned long long)(tk4 - tk3)); atomicAdd((unsigned long long*)&g_dbg[4], 1ull);
+      atomicAdd((unsigned long long*)&g_dbg[5], (unsigned long long)(tkA - tk0)); atomicAdd((unsigned long long*)&g_dbg[6], (unsigned long long)(tkB - tkA)); } }
 #endif
 }
 
@@ -1135,7 +1138,7 @@ class DevHip {
     float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_));
     out[6] = ms * 1000.0 / nSweeps;
 #ifdef S4B_CONTROL_TIMING
-    { long long h[8]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h))); fprintf(stderr, "DBG control per-call us: stage %.2f decide %.2f propose %.2f out %.2f n=%lld\n", h[0]/100.0/h[4], h[1]/100.0/h[4], h[2]/100.0/h[4], h[3]/100.0/h[4], h[4]); }
+    { long long h[8]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h))); fprintf(stderr, "DBG control per-call us: stage %.2f (loads %.2f reduce %.2f) decide %.2f propose %.2f out %.2f n=%lld\n", h[0]/100.0/h[4], h[5]/100.0/h[4], h[6]/100.0/h[4], h[1]/100.0/h[4], h[2]/100.0/h[4], h[3]/100.0/h[4], h[4]); }
 #endif
   }
   void test_fits(double* out) {

@@ -114,15 +114,18 @@ template <class TR> S4B_HD inline int tv_depth(const TR& t, int n) {
 }
 
 // valid cut interval [lo, hi] of variable v at node n given the rules of its ancestors
-template <class TR> S4B_HD inline void tv_interval(const TR& t, const ModelView& m, int n, int v, int& lo, int& hi) {
-  lo = 0; hi = S4B_UNI(m.numCuts[v]) - 1;
+template <class TR> S4B_HD inline void tv_interval(const TR& t, const ModelView& m, int n, int v, int& loOut, int& hiOut) {
+  // locals + selects (not "if left then hi else lo"): the bounds must stay in registers on the device
+  int lo = 0, hi = S4B_UNI(m.numCuts[v]) - 1;
   int child = n;
   for (int a = t.parent.get(n); a >= 0; child = a, a = t.parent.get(a)) {
-    if (t.var.get(a) != v) continue;
-    int s = (int)t.cut.get(a);
-    if (child == t.left.get(a)) { if (s - 1 < hi) hi = s - 1; }
-    else { if (s + 1 > lo) lo = s + 1; }
+    const bool hit = t.var.get(a) == v;
+    const int s = (int)t.cut.get(a);
+    const bool isLeft = child == t.left.get(a);
+    hi = (hit && isLeft && s - 1 < hi) ? s - 1 : hi;
+    lo = (hit && !isLeft && s + 1 > lo) ? s + 1 : lo;
   }
+  loOut = lo; hiOut = hi;
 }
 
 // stackless walk of the subtree rooted at `root`:
