@@ -322,6 +322,45 @@ static size_t control_lds_bytes(int P, int logIntLen) { return ((size_t)P * 4 + 
 
 typedef TreeCacheT<WaveArr<int16_t>> WaveCache;
 
+// Generator as the control wave sees it: the state array stays in LDS, the position and the 64-word window
+// around it live in registers (lane l = mt[wbase + l]), so a draw is a v_readlane plus the tempering.
+struct WaveRng {
+  MTState* st; int mti; int wbase; uint32_t win;
+  __device__ __forceinline__ void open(MTState* s) { st = s; mti = S4B_UNI((int)s->mti); wbase = -64; win = 0u; }
+  __device__ __forceinline__ void close() { st->mti = mti; }
+};
+__device__ __forceinline__ uint32_t mt_next(WaveRng* r) {
+  int k = r->mti;
+  if (k >= 624) { mt_regenerate_wave(r->st); k = 0; r->wbase = -64; }
+  const int wb = k & ~63;
+  if (wb != r->wbase) {
+    const int idx = wb + (int)(threadIdx.x & 63);
+    r->win = idx < 624 ? r->st->mt[idx] : 0u;
+    r->wbase = wb;
+  }
+  uint32_t y = (uint32_t)__builtin_amdgcn_readlane((int)r->win, k & 63);
+  r->mti = k + 1;
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+// Model view of the control wave: the prior tables sit in registers (lane d / lane k), LDS only beyond 64 / 128
+struct WaveModel : ModelView {
+  WaveArrD pg, lpg, l1pg, li0, li1; int nc0, nc1;
+};
+__device__ __forceinline__ double mv_pg_depth(const WaveModel& m, int d) { return d < 64 ? m.pg.get(d) : S4B_UNI(m.pgDepth[d]); }
+__device__ __forceinline__ double mv_log_pg(const WaveModel& m, int d) { return d < 64 ? m.lpg.get(d) : S4B_UNI(m.logPg[d]); }
+__device__ __forceinline__ double mv_log1m_pg(const WaveModel& m, int d) { return d < 64 ? m.l1pg.get(d) : S4B_UNI(m.log1mPg[d]); }
+__device__ __forceinline__ double mv_log_int(const WaveModel& m, int k) {
+  return k < 64 ? m.li0.get(k) : (k < 128 ? m.li1.get(k - 64) : S4B_UNI(m.logInt[k]));
+}
+__device__ __forceinline__ int mv_num_cuts(const WaveModel& m, int v) {
+  return v < 64 ? __builtin_amdgcn_readlane(m.nc0, v) : (v < 128 ? __builtin_amdgcn_readlane(m.nc1, v - 64) : S4B_UNI(m.numCuts[v]));
+}
+
 __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ MTState s_rng;
@@ -449,9 +488,14 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
   s_rng.pad = 1;   // one whole wave owns the generator from here on: lane-parallel block regeneration
 
   // ---- wave 0: wave-uniform control code on register-resident arrays -------------------------------------
-  ModelView m = a.model;
+  WaveModel m;
+  static_cast<ModelView&>(m) = a.model;
   m.numCuts = numCuts; m.pgDepth = s_tab; m.logPg = s_tab + S4B_MAX_DEPTH; m.log1mPg = s_tab + 2 * S4B_MAX_DEPTH; m.logInt = logInt;
   m.scratch = s_scratch;
+  m.pg.load(s_tab[lane]); m.lpg.load(s_tab[S4B_MAX_DEPTH + lane]); m.l1pg.load(s_tab[2 * S4B_MAX_DEPTH + lane]);
+  m.li0.load(lane < m.logIntLen ? logInt[lane] : 0.0); m.li1.load(64 + lane < m.logIntLen ? logInt[64 + lane] : 0.0);
+  m.nc0 = lane < a.P ? numCuts[lane] : 0; m.nc1 = 64 + lane < a.P ? numCuts[64 + lane] : 0;
+  WaveRng rng; rng.open(&s_rng);
   if (doDecide) {
     WaveArrD binSum, binCnt;
     binSum.load(lane < nb ? ((s_red[0][0][lane] + s_red[0][1][lane]) + s_red[0][2][lane]) + s_red[0][3][lane] : 0.0);
@@ -459,7 +503,7 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
     DecideWork<WaveArrD> wk;
     wk.ll.load(0.0); wk.lc.load(0.0); wk.ls.load(0.0); wk.u1.load(0.5); wk.u2.load(0.5); wk.val.load(0.0);
     StepRecord rec; int32_t accepted = 0;
-    const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &s_rng, &s_prT, tbT, binCnt, binSum, wk, &accepted, &rec, caT);
+    const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &rng, &s_prT, tbT, binCnt, binSum, wk, &accepted, &rec, caT);
     const int cntOut = prT.hwm > hwmNew ? prT.hwm : hwmNew;
     wave_tree_store(curT, a.var + oT, a.cut + oT, a.left + oT, a.right + oT, a.parent + oT, cntOut, lane);
     if (lane < cntOut) { a.mu[oT + lane] = mu.mine(); a.cnt[oT + lane] = cnt.r; cT.muOld[lane] = muOld.mine(); cT.insub[lane] = (uint8_t)tbT.insub.r; }
@@ -483,7 +527,7 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
     }
     tbN.prop = curN;
     tbN.binA.r = -1; tbN.binB.r = -1; tbN.insub.r = 0; tbN.list.r = 0;
-    if (propose(curN, hwmN, m, &s_rng, &s_prN, tbN, caN) != 0 && lane == 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
+    if (propose(curN, hwmN, m, &rng, &s_prN, tbN, caN) != 0 && lane == 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
     const int cntOut = s_prN.hwm;
     wave_tree_store(tbN.prop, cN.pvar, cN.pcut, cN.pleft, cN.pright, cN.pparent, cntOut, lane);
     if (lane < cntOut) { cN.binA[lane] = (int16_t)tbN.binA.r; cN.binB[lane] = (int16_t)tbN.binB.r; cN.insub[lane] = (uint8_t)tbN.insub.r;
@@ -492,6 +536,7 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
   }
   S4B_TICK(tk3);
   // ---- RNG state back to global
+  rng.close();
   s_rng.pad = 0;
   for (int i = lane; i < (int)(sizeof(MTState) / 4); i += 64) ((uint32_t*)a.rng)[i] = ((const uint32_t*)&s_rng)[i];
 #ifdef S4B_CONTROL_TIMING

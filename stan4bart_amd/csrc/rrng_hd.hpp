@@ -39,7 +39,7 @@ struct MTState {
   int32_t pad;   // device only: 1 while a full wave owns the state (lane-parallel block regeneration), else 0
 };
 
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIPCC__)
 // The block recurrence mt[k] <- mt[k+397 mod 624] ^ f(mt[k], mt[k+1 mod 624]) only reaches back 227 positions
 // for its updated inputs, so 64 consecutive elements can be produced at once (reads of a chunk happen before
 // its writes: one wave, lockstep).  Same values as the sequential loop.
@@ -91,7 +91,7 @@ S4B_HD inline uint32_t mt_next(MTState* s) {
   return y;
 }
 
-S4B_HD inline double r_unif(MTState* s) {
+template <class RNG> S4B_HD inline double r_unif(RNG* s) {
   const double half_ulp = 0.5 * 2.328306437080797e-10;
   double v = (double)mt_next(s) * 2.3283064365386963e-10;
   if (v <= 0.0) return half_ulp;
@@ -150,7 +150,7 @@ S4B_HD inline double r_qnorm(double p) {
 }
 
 // norm_rand() with N01_kind = INVERSION
-S4B_HD inline double r_norm(MTState* s) {
+template <class RNG> S4B_HD inline double r_norm(RNG* s) {
   const double BIG = 134217728.0;
   double u = r_unif(s);
   u = (double)(int)(BIG * u) + r_unif(s);
@@ -158,7 +158,7 @@ S4B_HD inline double r_norm(MTState* s) {
 }
 
 // exp_rand() (Ahrens & Dieter 1972 as in R's sexp.c)
-S4B_HD inline double r_exp(MTState* s) {
+template <class RNG> S4B_HD inline double r_exp(RNG* s) {
   const double q[16] = {0.6931471805599453, 0.9333736875190459, 0.9888777961838675, 0.9984589039328340,
                         0.9998292811061389, 0.9999833164100727, 0.9999985691438767, 0.9999998906925558,
                         0.9999999924734159, 0.9999999995283275, 0.9999999999728814, 0.9999999999985598,
@@ -176,7 +176,7 @@ S4B_HD inline double r_exp(MTState* s) {
 }
 
 // uniform integer in [lo, hi) the way dbarts' ext_rng does it: lo + (int64)(u * range)
-S4B_HD inline int r_unif_int(MTState* s, int lo, int hi_excl) {
+template <class RNG> S4B_HD inline int r_unif_int(RNG* s, int lo, int hi_excl) {
   return lo + (int)(r_unif(s) * (double)(hi_excl - lo));
 }
 

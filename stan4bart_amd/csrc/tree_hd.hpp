@@ -78,6 +78,14 @@ enum { S4B_MAX_DEPTH_LOCAL = 1 };     // device code always passes an LDS scratc
 enum { S4B_MAX_DEPTH_LOCAL = S4B_MAX_DEPTH };
 #endif
 
+// table accessors: the device wave path overloads them for a model view whose tables live in registers
+S4B_HD inline double mv_pg_depth(const ModelView& m, int d) { return S4B_UNI(m.pgDepth[d]); }
+S4B_HD inline double mv_log_pg(const ModelView& m, int d) { return S4B_UNI(m.logPg[d]); }
+S4B_HD inline double mv_log1m_pg(const ModelView& m, int d) { return S4B_UNI(m.log1mPg[d]); }
+S4B_HD inline double mv_log_int(const ModelView& m, int k) { return S4B_UNI(m.logInt[k]); }
+S4B_HD inline int mv_num_cuts(const ModelView& m, int v) { return S4B_UNI(m.numCuts[v]); }
+
+
 // everything the O(N) kernels and decide() need to know about the pending move of one tree
 struct Proposal {
   int32_t type, status;      // status 1: MH step pending, -1: no valid proposal (no accept draw)
@@ -114,9 +122,9 @@ template <class TR> S4B_HD inline int tv_depth(const TR& t, int n) {
 }
 
 // valid cut interval [lo, hi] of variable v at node n given the rules of its ancestors
-template <class TR> S4B_HD inline void tv_interval(const TR& t, const ModelView& m, int n, int v, int& loOut, int& hiOut) {
+template <class TR, class MV> S4B_HD inline void tv_interval(const TR& t, const MV& m, int n, int v, int& loOut, int& hiOut) {
   // locals + selects (not "if left then hi else lo"): the bounds must stay in registers on the device
-  int lo = 0, hi = S4B_UNI(m.numCuts[v]) - 1;
+  int lo = 0, hi = mv_num_cuts(m, v) - 1;
   int child = n;
   for (int a = t.parent.get(n); a >= 0; child = a, a = t.parent.get(a)) {
     const bool hit = t.var.get(a) == v;
@@ -149,7 +157,7 @@ struct Walker {
 
 // number of predictors that still have a free cut at node n.  Only predictors used by an ancestor can be
 // exhausted; each is counted once (at its lowest ancestor)
-template <class TR> S4B_HD inline int tv_num_avail_compute(const TR& t, const ModelView& m, int n) {
+template <class TR, class MV> S4B_HD inline int tv_num_avail_compute(const TR& t, const MV& m, int n) {
   int exhausted = 0;
   for (int a = t.parent.get(n); a >= 0; a = t.parent.get(a)) {
     int v = t.var.get(a);
@@ -166,7 +174,7 @@ template <class TR> S4B_HD inline int tv_num_avail_compute(const TR& t, const Mo
 // Top-down: going from the parent to n only the parent's own predictor v can become exhausted (its interval
 // loses the side of the cut n is not on); everything else is inherited.  Requires the parent's memo (the
 // callers fill in pre-order).  Equals tv_num_avail_compute / tv_depth, which remain as the definition.
-template <class TR> S4B_HD inline void tv_fill_info_node(TR& t, const ModelView& m, int n) {
+template <class TR, class MV> S4B_HD inline void tv_fill_info_node(TR& t, const MV& m, int n) {
   const int par = t.parent.get(n);
   if (par < 0) { t.na.set(n, (int16_t)m.Pvalid); t.dep.set(n, 0); return; }
   const int v = t.var.get(par), s = (int)t.cut.get(par);
@@ -176,19 +184,19 @@ template <class TR> S4B_HD inline void tv_fill_info_node(TR& t, const ModelView&
   const int gone = (lo <= hi && loN > hiN) ? 1 : 0;
   t.na.set(n, (int16_t)((int)t.na.get(par) - gone)); t.dep.set(n, (int16_t)((int)t.dep.get(par) + 1));
 }
-template <class TR> S4B_HD inline void tv_fill_info(TR& t, const ModelView& m, int root) {
+template <class TR, class MV> S4B_HD inline void tv_fill_info(TR& t, const MV& m, int root) {
   int nd, k; Walker<TR> w(t, root);
   while (w.next(nd, k)) if (k != 2) tv_fill_info_node(t, m, nd);
 }
-template <class TR> S4B_HD inline int tv_num_avail(const TR& t, const ModelView&, int n) { return (int)t.na.get(n); }
+template <class TR, class MV> S4B_HD inline int tv_num_avail(const TR& t, const MV&, int n) { return (int)t.na.get(n); }
 template <class TR> S4B_HD inline int tv_depth_of(const TR& t, int n) { return (int)t.dep.get(n); }
-template <class TR> S4B_HD inline double tv_growth(const TR& t, const ModelView& m, int n) {
+template <class TR, class MV> S4B_HD inline double tv_growth(const TR& t, const MV& m, int n) {
   if (tv_num_avail(t, m, n) == 0) return 0.0;
-  return S4B_UNI(m.pgDepth[tv_depth_of(t, n)]);
+  return mv_pg_depth(m, tv_depth_of(t, n));
 }
 
 // the idx-th (0-based) predictor, in increasing order, that is available at node n
-template <class TR> S4B_HD inline int tv_nth_avail_var(const TR& t, const ModelView& m, int n, int idx) {
+template <class TR, class MV> S4B_HD inline int tv_nth_avail_var(const TR& t, const MV& m, int n, int idx) {
   if (m.Pvalid == m.P) {
     // fast path: only ancestors' predictors can be unavailable; bump the candidate past every exhausted
     // predictor <= it, smallest first
@@ -208,14 +216,14 @@ template <class TR> S4B_HD inline int tv_nth_avail_var(const TR& t, const ModelV
     }
   }
   for (int v = 0; v < m.P; ++v) {
-    if (m.numCuts[v] <= 0) continue;
+    if (mv_num_cuts(m, v) <= 0) continue;
     int lo, hi; tv_interval(t, m, n, v, lo, hi);
     if (lo <= hi) { if (idx == 0) return v; --idx; }
   }
   return -1;
 }
 
-template <class TR> S4B_HD inline int tv_draw_var(const TR& t, const ModelView& m, int n, MTState* rng) {
+template <class TR, class MV, class RNG> S4B_HD inline int tv_draw_var(const TR& t, const MV& m, int n, RNG* rng) {
   int good = tv_num_avail(t, m, n);
   int idx = r_unif_int(rng, 0, good);
   return tv_nth_avail_var(t, m, n, idx);
@@ -249,40 +257,40 @@ template <class TR, class AI16> S4B_HD inline int tv_list_swappable(const TR& t,
   while (w.next(nd, k)) if (k == 2 && !tv_is_nog(t, nd)) out.set(cnt++, (int16_t)nd);
   return cnt;
 }
-template <class TR, class AI16> S4B_HD inline int tv_list_growable(const TR& t, const ModelView& m, AI16& out) {   // DFS order
+template <class TR, class AI16, class MV> S4B_HD inline int tv_list_growable(const TR& t, const MV& m, AI16& out) {   // DFS order
   int cnt = 0, nd, k; Walker<TR> w(t, 0);
   while (w.next(nd, k)) if (k == 0 && tv_num_avail(t, m, nd) > 0) out.set(cnt++, (int16_t)nd);
   return cnt;
 }
-template <class TR> S4B_HD inline int tv_count_growable(const TR& t, const ModelView& m) {
+template <class TR, class MV> S4B_HD inline int tv_count_growable(const TR& t, const MV& m) {
   int cnt = 0, nd, k; Walker<TR> w(t, 0);
   while (w.next(nd, k)) if (k == 0 && tv_num_avail(t, m, nd) > 0) ++cnt;
   return cnt;
 }
 
 // P(birth step | tree) given the number of leaves that can still grow
-template <class TR> S4B_HD inline double tv_prob_birth_step(const TR& t, const ModelView& m, int numGrowable) {
+template <class TR, class MV> S4B_HD inline double tv_prob_birth_step(const TR& t, const MV& m, int numGrowable) {
   if (tv_is_leaf(t, 0)) return 1.0;
   return numGrowable > 0 ? m.pBirth : 0.0;
 }
 
 // log tree prior: own(n) + subtree(left) + subtree(right), associated exactly like the recursion
-template <class TR> S4B_HD inline double tv_log_prior(const TR& t, const ModelView& m) {
+template <class TR, class MV> S4B_HD inline double tv_log_prior(const TR& t, const MV& m) {
   double accLocal[S4B_MAX_DEPTH_LOCAL];
   double* acc = m.scratch ? m.scratch : accLocal;
   int depth = 0, nd, k; Walker<TR> w(t, 0);
   double result = 0.0;
   while (w.next(nd, k)) {
     if (k == 0) {
-      double v = tv_num_avail(t, m, nd) == 0 ? 0.0 /* log(1 - 0) */ : S4B_UNI(m.log1mPg[depth]);
+      double v = tv_num_avail(t, m, nd) == 0 ? 0.0 /* log(1 - 0) */ : mv_log1m_pg(m, depth);
       if (depth == 0) result = v; else acc[depth - 1] += v;
     } else if (k == 1) {
       int na = tv_num_avail(t, m, nd);
-      double r = na == 0 ? -INFINITY : S4B_UNI(m.logPg[depth]);
-      r += -S4B_UNI(m.logInt[na]);
+      double r = na == 0 ? -INFINITY : mv_log_pg(m, depth);
+      r += -mv_log_int(m, na);
       int lo, hi; tv_interval(t, m, nd, t.var.get(nd), lo, hi);
       int width = hi - lo + 1;
-      r += (width >= 1 && width < m.logIntLen) ? -S4B_UNI(m.logInt[width]) : -log((double)width);
+      r += (width >= 1 && width < m.logIntLen) ? -mv_log_int(m, width) : -log((double)width);
       acc[depth] = r;
       ++depth;
     } else {
@@ -295,18 +303,18 @@ template <class TR> S4B_HD inline double tv_log_prior(const TR& t, const ModelVi
 }
 
 // own term of node nd (at depth `depth`) in the log tree prior
-template <class TR> S4B_HD inline double tv_log_prior_own(const TR& t, const ModelView& m, int nd, int depth) {
+template <class TR, class MV> S4B_HD inline double tv_log_prior_own(const TR& t, const MV& m, int nd, int depth) {
   int na = tv_num_avail(t, m, nd);
-  if (t.var.get(nd) == NODE_LEAF) return na == 0 ? 0.0 : S4B_UNI(m.log1mPg[depth]);
-  double r = na == 0 ? -INFINITY : S4B_UNI(m.logPg[depth]);
-  r += -S4B_UNI(m.logInt[na]);
+  if (t.var.get(nd) == NODE_LEAF) return na == 0 ? 0.0 : mv_log1m_pg(m, depth);
+  double r = na == 0 ? -INFINITY : mv_log_pg(m, depth);
+  r += -mv_log_int(m, na);
   int lo, hi; tv_interval(t, m, nd, t.var.get(nd), lo, hi);
   int width = hi - lo + 1;
-  r += (width >= 1 && width < m.logIntLen) ? -S4B_UNI(m.logInt[width]) : -log((double)width);
+  r += (width >= 1 && width < m.logIntLen) ? -mv_log_int(m, width) : -log((double)width);
   return r;
 }
 // sum of the own terms over the subtree rooted at `root` (walk order)
-template <class TR> S4B_HD inline double tv_log_prior_subtree(const TR& t, const ModelView& m, int root) {
+template <class TR, class MV> S4B_HD inline double tv_log_prior_subtree(const TR& t, const MV& m, int root) {
   double sum = 0.0;
   int depth = tv_depth_of(t, root), nd, k; Walker<TR> w(t, root);
   while (w.next(nd, k)) {
@@ -330,7 +338,7 @@ struct TreeCacheT {
 };
 typedef TreeCacheT<PtrArr<int16_t>> TreeCache;
 
-template <class TR, class CA> S4B_HD inline void tv_recount(const TR& cur, const ModelView& m, CA& c) {
+template <class TR, class CA, class MV> S4B_HD inline void tv_recount(const TR& cur, const MV& m, CA& c) {
   int g = 0, gn = 0;
   for (int i = 0; i < c.nl; ++i) if (tv_num_avail(cur, m, c.leaf.get(i)) > 0) ++g;
   for (int i = 0; i < c.ni; ++i) if (tv_is_nog(cur, c.pre.get(i))) ++gn;
@@ -338,7 +346,7 @@ template <class TR, class CA> S4B_HD inline void tv_recount(const TR& cur, const
 }
 
 // (re)build memo + lists + log prior of `cur`
-template <class TR, class CA> S4B_HD inline void tv_rebuild_cache(TR& cur, const ModelView& m, CA& c) {
+template <class TR, class CA, class MV> S4B_HD inline void tv_rebuild_cache(TR& cur, const MV& m, CA& c) {
   tv_fill_info(cur, m, 0);
   int nl = 0, np = 0, nq = 0, nd, k; Walker<TR> w(cur, 0);
   while (w.next(nd, k)) {
@@ -370,7 +378,7 @@ template <class TR> S4B_HD inline void tv_min_max_split(const TR& t, int root, i
   while (w.next(nd, k)) if (k == 1 && t.var.get(nd) == v) { int s = (int)t.cut.get(nd); if (s < mn) mn = s; if (s > mx) mx = s; }
 }
 
-template <class TR> S4B_HD inline bool tv_rules_valid(const TR& t, const ModelView& m, int root) {
+template <class TR, class MV> S4B_HD inline bool tv_rules_valid(const TR& t, const MV& m, int root) {
   int nd, k; Walker<TR> w(t, root);
   while (w.next(nd, k)) if (k == 1) {
     int lo, hi; tv_interval(t, m, nd, t.var.get(nd), lo, hi);
@@ -385,8 +393,8 @@ template <class TR> S4B_HD inline bool tv_rules_valid(const TR& t, const ModelVi
 // structure cache `ca` of `cur` is valid (tv_rebuild_cache), the proposed tree is a copy of `cur` (memo
 // included) for node ids < hwm, and binA/binB = -1, insub = 0 there.
 // Returns 0, or -1 when the node capacity is exhausted (the caller raises an error).
-template <class TR, class TBL, class CA>
-S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* rng, Proposal* pr, TBL& tb, const CA& ca) {
+template <class TR, class TBL, class CA, class MV, class RNG>
+S4B_HD inline int propose(const TR& cur, int hwm, const MV& m, RNG* rng, Proposal* pr, TBL& tb, const CA& ca) {
   TR& pt = tb.prop;
   const int nl = ca.nl, ni = ca.ni;
   for (int i = 0; i < nl; ++i) tb.binA.set(ca.leaf.get(i), (int16_t)i);
@@ -408,7 +416,7 @@ S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* r
         pSelect = 1.0 / (double)g;
       }
       int depthNd = tv_depth_of(cur, nd);
-      double pgParent = S4B_UNI(m.pgDepth[depthNd]);      // nd is growable: numAvail > 0
+      double pgParent = mv_pg_depth(m, depthNd);      // nd is growable: numAvail > 0
       int v = tv_draw_var(cur, m, nd, rng);
       int lo, hi; tv_interval(cur, m, nd, v, lo, hi);
       int s = r_unif_int(rng, lo, hi + 1);
@@ -420,7 +428,7 @@ S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* r
       pt.var.set(L, NODE_LEAF); pt.left.set(L, -1); pt.right.set(L, -1); pt.parent.set(L, (int16_t)nd); pt.cut.set(L, 0);
       pt.var.set(R, NODE_LEAF); pt.left.set(R, -1); pt.right.set(R, -1); pt.parent.set(R, (int16_t)nd); pt.cut.set(R, 0);
       for (int i = hwm; i < h2; ++i) { tb.binA.set(i, -1); tb.binB.set(i, -1); tb.insub.set(i, 0); }
-      double pgChild = S4B_UNI(m.pgDepth[depthNd + 1]);
+      double pgChild = mv_pg_depth(m, depthNd + 1);
       tv_fill_info_node(pt, m, L); tv_fill_info_node(pt, m, R);
       int naL = tv_num_avail(pt, m, L), naR = tv_num_avail(pt, m, R);
       double pgL = naL == 0 ? 0.0 : pgChild, pgR = naR == 0 ? 0.0 : pgChild;
@@ -449,8 +457,8 @@ S4B_HD inline int propose(const TR& cur, int hwm, const ModelView& m, MTState* r
       int L = cur.left.get(nd), R = cur.right.get(nd);
       int depthNd = tv_depth_of(cur, nd);
       int naP = tv_num_avail(cur, m, nd), naL = tv_num_avail(cur, m, L), naR = tv_num_avail(cur, m, R);
-      double pgParent = naP == 0 ? 0.0 : S4B_UNI(m.pgDepth[depthNd]);
-      double pgC = S4B_UNI(m.pgDepth[depthNd + 1]);
+      double pgParent = naP == 0 ? 0.0 : mv_pg_depth(m, depthNd);
+      double pgC = mv_pg_depth(m, depthNd + 1);
       double pgL = naL == 0 ? 0.0 : pgC, pgR = naR == 0 ? 0.0 : pgC;
       double oldPrior = pgParent * (1.0 - pgL) * (1.0 - pgR);
       pt.var.set(nd, NODE_LEAF); pt.left.set(nd, -1); pt.right.set(nd, -1); pt.cut.set(nd, 0);
@@ -570,8 +578,8 @@ S4B_HD inline void leaves_draw(const AF64& lc, const AF64& ls, const AF64& u1, c
 template <class AF64>
 struct DecideWork { AF64 ll, lc, ls, u1, u2, val; };
 
-template <class TR, class TBL, class AF64, class AI32, class ABIN, class CA>
-S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, const ModelView& m, double sigma, MTState* rng,
+template <class TR, class TBL, class AF64, class AI32, class ABIN, class CA, class MV, class RNG>
+S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, const MV& m, double sigma, RNG* rng,
                          const Proposal* pr, TBL& tb, const ABIN& binCnt, const ABIN& binSum, DecideWork<AF64>& wk,
                          int32_t* accepted, StepRecord* rec, CA& ca) {
   TR& pt = tb.prop;
