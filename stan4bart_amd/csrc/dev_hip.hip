@@ -44,6 +44,34 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// NB independent sums over the 64 lanes at once: each halving step keeps one half of the values and hands the
+// other half to the partner lane, so the cross-lane traffic is NB-1 + log2(64/NB) exchanges instead of 6 NB.
+// Afterwards v[0] of lane l is the wave total of value wave_bin_of_lane<NB>(l).  Fixed order: deterministic.
+template <int CNT, int O, int NB, class T>
+__device__ __forceinline__ void wave_sum_bins_step(T (&v)[NB], int lane) {
+  if constexpr (CNT > 1) {
+    constexpr int h = CNT / 2;
+    const bool upper = (lane & O) != 0;
+#pragma unroll
+    for (int j = 0; j < h; ++j) {
+      const T send = upper ? v[j] : v[j + h];
+      const T keep = upper ? v[j + h] : v[j];
+      v[j] = keep + __shfl_xor(send, O, 64);
+    }
+    wave_sum_bins_step<h, O / 2, NB, T>(v, lane);
+  } else if constexpr (O > 0) {
+    v[0] += __shfl_xor(v[0], O, 64);
+    wave_sum_bins_step<1, O / 2, NB, T>(v, lane);
+  }
+}
+template <int NB, class T>
+__device__ __forceinline__ void wave_sum_bins(T (&v)[NB], int lane) { wave_sum_bins_step<NB, 32, NB, T>(v, lane); }
+template <int NB>
+__device__ __forceinline__ int wave_bin_of_lane(int lane) {
+  // NB = 2^q: the q halving steps use lane bits 5, 4, ..., 6-q for value-index bits q-1, ..., 0
+  constexpr int q = NB == 16 ? 4 : NB == 8 ? 3 : NB == 4 ? 2 : NB == 2 ? 1 : 0;
+  return q == 0 ? 0 : (lane >> (6 - q)) & (NB - 1);
+}
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
@@ -55,6 +83,12 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+#ifdef S4B_CONTROL_TIMING
+__device__ long long g_dbg[16];
+#define S4B_TICK(x) long long x = wall_clock64()
+#else
+#define S4B_TICK(x)
+#endif
 // ------------------------------------------------------------------------------------------------
 // k_tree: the O(N) kernel of one tree update.  One pass over the observations:
 //   apply half  (tree t-1, already decided):  R_i += mu_old[leaf] - mu_new[leaf'], relabel under the accepted move
@@ -176,16 +210,11 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
       }
     }
   }
-  // block reduction, fixed order: xor-butterfly inside each wave, then waves 0..3 in order
+  // block reduction, fixed order: transposed halving inside each wave, then waves 0..3 in order
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    const double s = wave_sum(accS[k]);
-    int c = accN[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if (lane == 0) { L.redS[wv * NBMAX + k] = s; L.redN[wv * NBMAX + k] = c; }
-  }
+  wave_sum_bins<NB>(accS, lane);
+  wave_sum_bins<NB>(accN, lane);
+  if ((lane & (64 / NB - 1)) == 0) { const int k = wave_bin_of_lane<NB>(lane); L.redS[wv * NBMAX + k] = accS[0]; L.redN[wv * NBMAX + k] = accN[0]; }
   __syncthreads();
   if ((int)threadIdx.x < NB && base + (int)threadIdx.x < nbTotal) {
     const int k = threadIdx.x;
@@ -201,6 +230,7 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
 template <bool APPLY>
 __global__ __launch_bounds__(BLOCK) void k_tree(BartArrays a, int t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  S4B_TICK(tq0);
   const StepScratch& c = a.sc[t & 1];
   const Proposal pr = *c.prop;
   const TreeLds L = carve_tree(smem, a.nc);
@@ -223,6 +253,7 @@ __global__ __launch_bounds__(BLOCK) void k_tree(BartArrays a, int t) {
     }
   }
   __syncthreads();
+  S4B_TICK(tq1);
   const int nb = pr.nbA + pr.nbB;
   if (nb <= 4) tree_pass<4, APPLY>(a, t, L, pr.node, prevRoot, prevAcc, 0, nb);
   else if (nb <= 8) tree_pass<8, APPLY>(a, t, L, pr.node, prevRoot, prevAcc, 0, nb);
@@ -231,6 +262,13 @@ __global__ __launch_bounds__(BLOCK) void k_tree(BartArrays a, int t) {
     // further bin passes read the residual this thread has just written
     for (int base = NBMAX; base < nb; base += NBMAX) tree_pass<NBMAX, false>(a, t, L, pr.node, prevRoot, prevAcc, base, nb);
   }
+#ifdef S4B_CONTROL_TIMING
+  { S4B_TICK(tq2);
+    if (APPLY && threadIdx.x == 0) { atomicAdd((unsigned long long*)&g_dbg[8], (unsigned long long)(tq1 - tq0)); atomicAdd((unsigned long long*)&g_dbg[9], (unsigned long long)(tq2 - tq1));
+      atomicAdd((unsigned long long*)&g_dbg[10], 1ull);
+      atomicMin((unsigned long long*)&g_dbg[11], (unsigned long long)tq0); atomicMax((unsigned long long*)&g_dbg[12], (unsigned long long)tq2);
+      atomicMax((unsigned long long*)&g_dbg[13], (unsigned long long)tq0); } }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -306,12 +344,6 @@ __device__ __forceinline__ void wave_tree_store(const WaveTree& t, int16_t* var,
                       parent[lane] = (int16_t)t.parent.r; }
 }
 
-#ifdef S4B_CONTROL_TIMING
-__device__ long long g_dbg[8];
-#define S4B_TICK(x) long long x = wall_clock64()
-#else
-#define S4B_TICK(x)
-#endif
 // slow path for trees with more than 64 node slots in use: the sequential code straight on the global arrays
 __device__ __attribute__((noinline)) void control_global_path(BartArrays a, int t, int next, double* scratch) {
   a.model.scratch = scratch;
@@ -468,10 +500,12 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
     return;
   }
   if (doDecide) {
+    {   // 8 sums + 8 counts of this wave's share of the partials in one transposed reduction
+      double pv[16];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (j < nb) {
-      const double ss = wave_sum(ps[j]), cc = wave_sum(pc[j]);
-      if (lane == 0) { s_red[0][wv][j] = ss; s_red[1][wv][j] = cc; }
+      for (int j = 0; j < 8; ++j) { pv[j] = ps[j]; pv[8 + j] = pc[j]; }
+      wave_sum_bins<16>(pv, lane);
+      if ((lane & 3) == 0) { const int k = wave_bin_of_lane<16>(lane); s_red[k >> 3][wv][k & 7] = pv[0]; }
     }
     for (int k = 8; k < nb; ++k) {   // rare: more than 8 bins
       double s = 0.0, c = 0.0;
@@ -1183,7 +1217,8 @@ class DevHip {
     float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_));
     out[6] = ms * 1000.0 / nSweeps;
 #ifdef S4B_CONTROL_TIMING
-    { long long h[8]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h))); fprintf(stderr, "DBG control per-call us: stage %.2f (loads %.2f reduce %.2f) decide %.2f propose %.2f out %.2f n=%lld\n", h[0]/100.0/h[4], h[5]/100.0/h[4], h[6]/100.0/h[4], h[1]/100.0/h[4], h[2]/100.0/h[4], h[3]/100.0/h[4], h[4]); }
+    { long long h[16]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h)));
+      fprintf(stderr, "DBG k_tree per-WG us: stage %.2f pass %.2f (n=%lld)\n", h[8]/100.0/h[10], h[9]/100.0/h[10], h[10]); fprintf(stderr, "DBG control per-call us: stage %.2f (loads %.2f reduce %.2f) decide %.2f propose %.2f out %.2f n=%lld\n", h[0]/100.0/h[4], h[5]/100.0/h[4], h[6]/100.0/h[4], h[1]/100.0/h[4], h[2]/100.0/h[4], h[3]/100.0/h[4], h[4]); }
 #endif
   }
   void test_fits(double* out) {
