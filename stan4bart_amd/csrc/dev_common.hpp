@@ -16,7 +16,7 @@ struct ScaleState {
   double sigma;                // sigmaData / range
 };
 
-enum : int32_t { S4B_ERR_NODE_CAPACITY = 1, S4B_ERR_TRACE_OVERFLOW = 2 };
+enum : int32_t { S4B_ERR_NODE_CAPACITY = 1, S4B_ERR_TRACE_OVERFLOW = 2, S4B_ERR_INTERNAL = 4 };
 
 struct StepScratch {
   int16_t *pvar, *pleft, *pright, *pparent; uint16_t* pcut;

@@ -357,8 +357,8 @@ typedef TreeCacheT<WaveArr<int16_t>> WaveCache;
 // Generator as the control wave sees it: the state array stays in LDS, the position and the 64-word window
 // around it live in registers (lane l = mt[wbase + l]), so a draw is a v_readlane plus the tempering.
 struct WaveRng {
-  MTState* st; int mti; int wbase; uint32_t win;
-  __device__ __forceinline__ void open(MTState* s) { st = s; mti = S4B_UNI((int)s->mti); wbase = -64; win = 0u; }
+  MTState* st; int mti; int wbase; uint32_t win; int count;   // count: draws since open() / since it was last zeroed
+  __device__ __forceinline__ void open(MTState* s) { st = s; mti = S4B_UNI((int)s->mti); wbase = -64; win = 0u; count = 0; }
   __device__ __forceinline__ void close() { st->mti = mti; }
 };
 __device__ __forceinline__ uint32_t mt_next(WaveRng* r) {
@@ -371,7 +371,7 @@ __device__ __forceinline__ uint32_t mt_next(WaveRng* r) {
     r->wbase = wb;
   }
   uint32_t y = (uint32_t)__builtin_amdgcn_readlane((int)r->win, k & 63);
-  r->mti = k + 1;
+  r->mti = k + 1; ++r->count;
   y ^= (y >> 11);
   y ^= (y << 7) & 0x9d2c5680u;
   y ^= (y << 15) & 0xefc60000u;
@@ -393,15 +393,44 @@ __device__ __forceinline__ int mv_num_cuts(const WaveModel& m, int v) {
   return v < 64 ? __builtin_amdgcn_readlane(m.nc0, v) : (v < 128 ? __builtin_amdgcn_readlane(m.nc1, v - 64) : S4B_UNI(m.numCuts[v]));
 }
 
-__global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ MTState s_rng;
-  __shared__ double s_tab[3 * S4B_MAX_DEPTH];
-  __shared__ double s_scratch[S4B_MAX_DEPTH];
-  __shared__ double s_red[2][BLOCK / 64][64];
-  __shared__ Proposal s_prT, s_prN;
+// Workgroup of 8 waves with fixed roles, tied together by two LDS hand-shakes (no workgroup barrier after start-up):
+//   wave 0        decide(t): waits for the bin totals, accept/reject, leaf draws, writes tree t, names the winner
+//   waves 4, 5    candidates: draw the proposal of tree `next` from the generator position decide(t) will leave behind —
+//                 that position is known up to one bit before the statistics arrive: decide consumes one uniform for the
+//                 accept test plus two per leaf of the tree it ends with, i.e. d + 2 nl (reject) or d + 2 nl' (accept).
+//                 Each candidate advances a private copy of the generator by its hypothesis and runs propose() while
+//                 wave 0 is still waiting / deciding; the one whose hypothesis matches the draws actually consumed
+//                 publishes its tables and generator state.  A leaf without observations (no draw) breaks both
+//                 hypotheses: then wave 0 proposes itself, as it does at the start of a sweep.
+//   waves 1-3,6,7 reducers: per-workgroup partials -> bin totals (fixed order)
+constexpr int CBLOCK = 512;
+constexpr int C_NRED = 5;
+struct ControlShared {
+  MTState rng[3];                        // slot 0: wave 0, slots 1, 2: candidates
+  double scratch[3][S4B_MAX_DEPTH];
+  double red[2][C_NRED][64];             // [sum | count][reducer][bin]
+  Proposal prT, prN[3];
+  int arrived, verdict;
+};
+__device__ __forceinline__ void spin_until(int* flag, int target, int32_t* errFlag) {
+  int guard = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++guard > (1 << 24)) { *errFlag |= S4B_ERR_INTERNAL; break; }   // never hang the device on a logic error
+  }
+}
+__device__ __forceinline__ void rng_advance(WaveRng* r, int k) {
+  int total = r->mti + k;
+  while (total > 624) { mt_regenerate_wave(r->st); total -= 624; }
+  r->mti = total; r->wbase = -64;
+}
+
+__global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int next) {
+  __shared__ ControlShared S;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   S4B_TICK(tk0);
+  if (threadIdx.x == 0) { S.arrived = 0; S.verdict = 0; }
+  __syncthreads();
   const bool doDecide = t >= 0, doPropose = next >= 0;
   const int tt = doDecide ? t : 0, tn = doPropose ? next : 0;
   const StepScratch& cT = a.sc[tt & 1];
@@ -410,174 +439,219 @@ __global__ __launch_bounds__(BLOCK) void k_control(BartArrays a, int t, int next
   const size_t oT = (size_t)tt * nc, oN = (size_t)tn * nc;
   const bool laneIn = lane < nc;
   const int li = laneIn ? lane : 0;
+  const bool isDecider = wv == 0, isCand = wv == 4 || wv == 5;
+  const int candIdx = wv - 4;                                  // 0 / 1 for the candidate waves
+  const int redIdx = wv < 4 ? wv - 1 : wv - 3;                 // 0..4 for the reducer waves
 
-  // ---- hop 1: every global load of the step is issued up front, none depends on another -----------------
+  // ---- scalars every role needs (path selection, hypotheses): one hop
   Proposal prT = *cT.prop;
   const int hwmT = a.hwm[tt], hwmN = a.hwm[tn];
-  const int cvalidT = a.cvalid[tt], cvalidN = a.cvalid[tn];
-  const int cnlT = a.cnl[tt], cnlN = a.cnl[tn], cniN = a.cni[tn];
-  const double clogpiN = a.clogpi[tn];
-  const double sigma = a.scale->sigma;
-  // wave 0 registers (lane i = node slot i / list position i); harmless for the other waves
-  WaveTree curT, curN; WaveTables tbT, tbN; WaveCache caT, caN;
-  WaveArrD mu, muOld; WaveArr<int32_t> cnt;
-  curT.var.r = a.var[oT + li]; curT.cut.r = a.cut[oT + li]; curT.left.r = a.left[oT + li]; curT.right.r = a.right[oT + li];
-  curT.parent.r = a.parent[oT + li]; curT.na.r = a.cna[oT + li]; curT.dep.r = a.cdep[oT + li]; curT.nc = nc < 64 ? nc : 64;
-  tbT.prop.var.r = cT.pvar[li]; tbT.prop.cut.r = cT.pcut[li]; tbT.prop.left.r = cT.pleft[li]; tbT.prop.right.r = cT.pright[li];
-  tbT.prop.parent.r = cT.pparent[li]; tbT.prop.na.r = cT.pna[li]; tbT.prop.dep.r = cT.pdep[li]; tbT.prop.nc = curT.nc;
-  tbT.binA.r = cT.binA[li]; tbT.binB.r = cT.binB[li]; tbT.insub.r = cT.insub[li]; tbT.list.r = 0;
-  caT.leaf.r = a.cleaf[oT + li]; caT.pre.r = a.cpre[oT + li]; caT.post.r = a.cpost[oT + li]; caT.nl = cnlT; caT.ni = a.cni[tt];
-  caT.g = a.cg[tt]; caT.gn = a.cgn[tt]; caT.logPi = a.clogpi[tt]; caT.valid = cvalidT;
-  mu.load(a.mu[oT + li]); muOld.load(0.0); cnt.r = a.cnt[oT + li];
-  curN.var.r = a.var[oN + li]; curN.cut.r = a.cut[oN + li]; curN.left.r = a.left[oN + li]; curN.right.r = a.right[oN + li];
-  curN.parent.r = a.parent[oN + li]; curN.na.r = a.cna[oN + li]; curN.dep.r = a.cdep[oN + li]; curN.nc = curT.nc;
-  caN.leaf.r = a.cleaf[oN + li]; caN.pre.r = a.cpre[oN + li]; caN.post.r = a.cpost[oN + li];
-  caN.nl = cnlN; caN.ni = cniN; caN.g = a.cg[tn]; caN.gn = a.cgn[tn]; caN.logPi = clogpiN; caN.valid = cvalidN;
-  // partials of the first 8 bins (whether or not the proposal has that many: the grid-sized slabs exist) and the small
-  // shared state, all fetched in this same hop: fixed-trip, predicated loads first, uses afterwards
-  double ps[8], pc[8];
-  {
-    const int b0 = threadIdx.x, b1 = threadIdx.x + BLOCK;
-    const bool in0 = doDecide && b0 < a.grid, in1 = doDecide && b1 < a.grid;
-    double qs[8], qc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      ps[j] = in0 ? a.partSum[(size_t)j * a.grid + b0] : 0.0; pc[j] = in0 ? a.partCnt[(size_t)j * a.grid + b0] : 0.0;
-      qs[j] = in1 ? a.partSum[(size_t)j * a.grid + b1] : 0.0; qc[j] = in1 ? a.partCnt[(size_t)j * a.grid + b1] : 0.0;
-    }
-    constexpr int MTW = (int)(sizeof(MTState) / 4), MTJ = (MTW + BLOCK - 1) / BLOCK;
-    uint32_t mtw[MTJ];
-#pragma unroll
-    for (int j = 0; j < MTJ; ++j) { const int i = threadIdx.x + j * BLOCK; mtw[j] = i < MTW ? ((const uint32_t*)a.rng)[i] : 0u; }
-    int32_t* numCuts = (int32_t*)smem;
-    double* logInt = (double*)(smem + ((size_t)a.P * 4 + 15) / 16 * 16);
-    const int i0 = threadIdx.x;
-    const int32_t nc0 = i0 < a.P ? a.numCuts[i0] : 0;
-    const double li0 = i0 < a.model.logIntLen ? a.model.logInt[i0] : 0.0;
-    double tb0 = 0.0, tb1 = 0.0, tb2 = 0.0;
-    if (i0 < S4B_MAX_DEPTH) { tb0 = a.model.pgDepth[i0]; tb1 = a.model.logPg[i0]; tb2 = a.model.log1mPg[i0]; }
-    // ---- uses
-#pragma unroll
-    for (int j = 0; j < MTJ; ++j) { const int i = threadIdx.x + j * BLOCK; if (i < MTW) ((uint32_t*)&s_rng)[i] = mtw[j]; }
-    if (i0 < a.P) numCuts[i0] = nc0;
-    if (i0 < a.model.logIntLen) logInt[i0] = li0;
-    if (i0 < S4B_MAX_DEPTH) { s_tab[i0] = tb0; s_tab[S4B_MAX_DEPTH + i0] = tb1; s_tab[2 * S4B_MAX_DEPTH + i0] = tb2; }
-    for (int i = threadIdx.x + BLOCK; i < a.P; i += BLOCK) numCuts[i] = a.numCuts[i];
-    for (int i = threadIdx.x + BLOCK; i < a.model.logIntLen; i += BLOCK) logInt[i] = a.model.logInt[i];
-    for (int i = threadIdx.x + BLOCK; i < S4B_MAX_DEPTH; i += BLOCK) {
-      s_tab[i] = a.model.pgDepth[i]; s_tab[S4B_MAX_DEPTH + i] = a.model.logPg[i]; s_tab[2 * S4B_MAX_DEPTH + i] = a.model.log1mPg[i];
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { ps[j] += qs[j]; pc[j] += qc[j]; }
-    if (doDecide) {
-      for (int b = threadIdx.x + 2 * BLOCK; b < a.grid; b += BLOCK) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { ps[j] += a.partSum[(size_t)j * a.grid + b]; pc[j] += a.partCnt[(size_t)j * a.grid + b]; }
-      }
-    }
-  }
-  int32_t* numCuts = (int32_t*)smem;
-  double* logInt = (double*)(smem + ((size_t)a.P * 4 + 15) / 16 * 16);
-
-  // ---- path selection (uniform over the workgroup) -----------------------------------------------------
   int need = 0, nb = 0;
   if (doDecide) { need = prT.hwm > hwmT ? prT.hwm : hwmT; nb = prT.nbA + prT.nbB; }
   if (doPropose && hwmN + 2 > need) need = hwmN + 2;
   const bool wavePath = need <= 64 && nb <= 64 && need <= nc + 2;
-  S4B_TICK(tkA);
-  if (!wavePath) {   // large tree: sequential code straight on the global arrays
-    if (doDecide) {
-      for (int k = wv; k < nb; k += BLOCK / 64) {
-        double s = 0.0, c = 0.0;
-        for (int b = lane; b < a.grid; b += 64) { s += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
-        s = wave_sum(s); c = wave_sum(c);
-        if (lane == 0) { a.binSum[k] = s; a.binCnt[k] = c; }
+  // generator positions decide(t) can end at (see above); candidate 1 only exists when accepting changes the leaf count
+  const int drawsAccept = (doDecide && prT.status == 1) ? 1 : 0;
+  const int nlNow = prT.nbA;
+  const int nlAcc = prT.type == MOVE_BIRTH ? nlNow + 1 : (prT.type == MOVE_DEATH ? nlNow - 1 : nlNow);
+  const int hyp0 = drawsAccept + 2 * nlNow, hyp1 = drawsAccept + 2 * nlAcc;
+  const bool spec = doDecide && doPropose && next != t && wavePath;
+  const bool cand1Exists = spec && drawsAccept == 1 && hyp1 != hyp0;
+
+  // ================================================================ reducers
+  if (!isDecider && !isCand) {
+    if (!doDecide) return;
+    const int ridx = redIdx * 64 + lane;
+    constexpr int RT = C_NRED * 64;
+    if (wavePath) {
+      double pv[16];
+      {
+        const int b0 = ridx, b1 = ridx + RT;
+        const bool in0 = b0 < a.grid, in1 = b1 < a.grid;
+        double qv[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pv[j] = in0 ? a.partSum[(size_t)j * a.grid + b0] : 0.0; pv[8 + j] = in0 ? a.partCnt[(size_t)j * a.grid + b0] : 0.0;
+          qv[j] = in1 ? a.partSum[(size_t)j * a.grid + b1] : 0.0; qv[8 + j] = in1 ? a.partCnt[(size_t)j * a.grid + b1] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) pv[j] += qv[j];
+        for (int b = ridx + 2 * RT; b < a.grid; b += RT) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { pv[j] += a.partSum[(size_t)j * a.grid + b]; pv[8 + j] += a.partCnt[(size_t)j * a.grid + b]; }
+        }
+      }
+      wave_sum_bins<16>(pv, lane);
+      if ((lane & 3) == 0) { const int k = wave_bin_of_lane<16>(lane); S.red[k >> 3][redIdx][k & 7] = pv[0]; }
+      for (int k = 8; k < nb; ++k) {   // rare: more than 8 bins
+        double sm = 0.0, c = 0.0;
+        for (int b = ridx; b < a.grid; b += RT) { sm += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
+        sm = wave_sum(sm); c = wave_sum(c);
+        if (lane == 0) { S.red[0][redIdx][k] = sm; S.red[1][redIdx][k] = c; }
+      }
+    } else {   // large tree: totals of every bin to global memory for the sequential path
+      for (int k = redIdx; k < nb; k += C_NRED) {
+        double sm = 0.0, c = 0.0;
+        for (int b = lane; b < a.grid; b += 64) { sm += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
+        sm = wave_sum(sm); c = wave_sum(c);
+        if (lane == 0) { a.binSum[k] = sm; a.binCnt[k] = c; }
       }
       __threadfence();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) control_global_path(a, t, next, s_scratch);
+    if (lane == 0) __hip_atomic_fetch_add(&S.arrived, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     return;
   }
-  if (doDecide) {
-    {   // 8 sums + 8 counts of this wave's share of the partials in one transposed reduction
-      double pv[16];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { pv[j] = ps[j]; pv[8 + j] = pc[j]; }
-      wave_sum_bins<16>(pv, lane);
-      if ((lane & 3) == 0) { const int k = wave_bin_of_lane<16>(lane); s_red[k >> 3][wv][k & 7] = pv[0]; }
-    }
-    for (int k = 8; k < nb; ++k) {   // rare: more than 8 bins
-      double s = 0.0, c = 0.0;
-      for (int b = threadIdx.x; b < a.grid; b += BLOCK) { s += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
-      s = wave_sum(s); c = wave_sum(c);
-      if (lane == 0) { s_red[0][wv][k] = s; s_red[1][wv][k] = c; }
-    }
-    if (threadIdx.x == 0) s_prT = prT;
+  if (!wavePath) {   // large tree: sequential code straight on the global arrays (one lane), no candidates
+    if (isCand) return;
+    if (doDecide) spin_until(&S.arrived, C_NRED, a.errFlag);
+    if (threadIdx.x == 0) control_global_path(a, t, next, S.scratch[0]);
+    return;
   }
-  S4B_TICK(tkB);
-  __syncthreads();
-  if (wv != 0) return;
-  S4B_TICK(tk1);
-  s_rng.pad = 1;   // one whole wave owns the generator from here on: lane-parallel block regeneration
+  if (isCand && (!spec || (candIdx == 1 && !cand1Exists))) return;
 
-  // ---- wave 0: wave-uniform control code on register-resident arrays -------------------------------------
+  // ================================================================ decider and candidates: register-resident state
+  const int slot = isCand ? 1 + candIdx : 0;
   WaveModel m;
-  static_cast<ModelView&>(m) = a.model;
-  m.numCuts = numCuts; m.pgDepth = s_tab; m.logPg = s_tab + S4B_MAX_DEPTH; m.log1mPg = s_tab + 2 * S4B_MAX_DEPTH; m.logInt = logInt;
-  m.scratch = s_scratch;
-  m.pg.load(s_tab[lane]); m.lpg.load(s_tab[S4B_MAX_DEPTH + lane]); m.l1pg.load(s_tab[2 * S4B_MAX_DEPTH + lane]);
-  m.li0.load(lane < m.logIntLen ? logInt[lane] : 0.0); m.li1.load(64 + lane < m.logIntLen ? logInt[64 + lane] : 0.0);
-  m.nc0 = lane < a.P ? numCuts[lane] : 0; m.nc1 = 64 + lane < a.P ? numCuts[64 + lane] : 0;
-  WaveRng rng; rng.open(&s_rng);
-  if (doDecide) {
-    WaveArrD binSum, binCnt;
-    binSum.load(lane < nb ? ((s_red[0][0][lane] + s_red[0][1][lane]) + s_red[0][2][lane]) + s_red[0][3][lane] : 0.0);
-    binCnt.load(lane < nb ? ((s_red[1][0][lane] + s_red[1][1][lane]) + s_red[1][2][lane]) + s_red[1][3][lane] : 0.0);
-    DecideWork<WaveArrD> wk;
-    wk.ll.load(0.0); wk.lc.load(0.0); wk.ls.load(0.0); wk.u1.load(0.5); wk.u2.load(0.5); wk.val.load(0.0);
-    StepRecord rec; int32_t accepted = 0;
-    const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &rng, &s_prT, tbT, binCnt, binSum, wk, &accepted, &rec, caT);
-    const int cntOut = prT.hwm > hwmNew ? prT.hwm : hwmNew;
-    wave_tree_store(curT, a.var + oT, a.cut + oT, a.left + oT, a.right + oT, a.parent + oT, cntOut, lane);
-    if (lane < cntOut) { a.mu[oT + lane] = mu.mine(); a.cnt[oT + lane] = cnt.r; cT.muOld[lane] = muOld.mine(); cT.insub[lane] = (uint8_t)tbT.insub.r; }
-    if (accepted) {   // the structure cache moved with the tree: keep the global copy current
-      if (lane < cntOut) { a.cna[oT + lane] = (int16_t)curT.na.r; a.cdep[oT + lane] = (int16_t)curT.dep.r; }
-      if (laneIn) { a.cleaf[oT + lane] = (int16_t)caT.leaf.r; a.cpre[oT + lane] = (int16_t)caT.pre.r; a.cpost[oT + lane] = (int16_t)caT.post.r; }
-      if (lane == 0) { a.cnl[t] = caT.nl; a.cni[t] = caT.ni; a.cg[t] = caT.g; a.cgn[t] = caT.gn; a.clogpi[t] = caT.logPi; }
+  static_cast<ModelView&>(m) = a.model;           // overflow pointers (depth >= 64, tables beyond 128 entries) stay global
+  m.scratch = S.scratch[slot];
+  m.pg.load(a.model.pgDepth[lane]); m.lpg.load(a.model.logPg[lane]); m.l1pg.load(a.model.log1mPg[lane]);
+  m.li0.load(lane < m.logIntLen ? a.model.logInt[lane] : 0.0); m.li1.load(64 + lane < m.logIntLen ? a.model.logInt[64 + lane] : 0.0);
+  m.nc0 = lane < a.P ? a.numCuts[lane] : 0; m.nc1 = 64 + lane < a.P ? a.numCuts[64 + lane] : 0;
+  {   // private copy of the generator
+    constexpr int MTW = (int)(sizeof(MTState) / 4), MTJ = (MTW + 63) / 64;
+    uint32_t mtw[MTJ];
+#pragma unroll
+    for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; mtw[j] = i < MTW ? ((const uint32_t*)a.rng)[i] : 0u; }
+#pragma unroll
+    for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; if (i < MTW) ((uint32_t*)&S.rng[slot])[i] = mtw[j]; }
+  }
+  WaveTree curT, curN; WaveTables tbT, tbN; WaveCache caT, caN;
+  WaveArrD mu, muOld; WaveArr<int32_t> cnt;
+  double sigma = 0.0;
+  curN.var.r = a.var[oN + li]; curN.cut.r = a.cut[oN + li]; curN.left.r = a.left[oN + li]; curN.right.r = a.right[oN + li];
+  curN.parent.r = a.parent[oN + li]; curN.na.r = a.cna[oN + li]; curN.dep.r = a.cdep[oN + li]; curN.nc = nc < 64 ? nc : 64;
+  caN.leaf.r = a.cleaf[oN + li]; caN.pre.r = a.cpre[oN + li]; caN.post.r = a.cpost[oN + li];
+  caN.nl = a.cnl[tn]; caN.ni = a.cni[tn]; caN.g = a.cg[tn]; caN.gn = a.cgn[tn]; caN.logPi = a.clogpi[tn]; caN.valid = a.cvalid[tn];
+  if (isDecider) {
+    sigma = a.scale->sigma;
+    curT.var.r = a.var[oT + li]; curT.cut.r = a.cut[oT + li]; curT.left.r = a.left[oT + li]; curT.right.r = a.right[oT + li];
+    curT.parent.r = a.parent[oT + li]; curT.na.r = a.cna[oT + li]; curT.dep.r = a.cdep[oT + li]; curT.nc = curN.nc;
+    tbT.prop.var.r = cT.pvar[li]; tbT.prop.cut.r = cT.pcut[li]; tbT.prop.left.r = cT.pleft[li]; tbT.prop.right.r = cT.pright[li];
+    tbT.prop.parent.r = cT.pparent[li]; tbT.prop.na.r = cT.pna[li]; tbT.prop.dep.r = cT.pdep[li]; tbT.prop.nc = curN.nc;
+    tbT.binA.r = cT.binA[li]; tbT.binB.r = cT.binB[li]; tbT.insub.r = cT.insub[li]; tbT.list.r = 0;
+    caT.leaf.r = a.cleaf[oT + li]; caT.pre.r = a.cpre[oT + li]; caT.post.r = a.cpost[oT + li]; caT.nl = a.cnl[tt]; caT.ni = a.cni[tt];
+    caT.g = a.cg[tt]; caT.gn = a.cgn[tt]; caT.logPi = a.clogpi[tt]; caT.valid = a.cvalid[tt];
+    mu.load(a.mu[oT + li]); muOld.load(0.0); cnt.r = a.cnt[oT + li];
+  }
+  WaveRng rng; rng.open(&S.rng[slot]);
+  S4B_TICK(tkA);
+  S4B_TICK(tkB);
+  S4B_TICK(tk2);
+  bool proposer = false;
+  if (isCand) {
+    rng_advance(&rng, candIdx == 0 ? hyp0 : hyp1);
+    proposer = true;
+  } else {
+    int winner = 0;
+    if (doDecide) {
+      S.prT = prT;
+      spin_until(&S.arrived, C_NRED, a.errFlag);
+#ifdef S4B_CONTROL_TIMING
+      tkB = wall_clock64();
+#endif
+      WaveArrD binSum, binCnt;
+      {
+        double sSum = 0.0, sCnt = 0.0;
+        if (lane < nb) {
+          sSum = S.red[0][0][lane]; sCnt = S.red[1][0][lane];
+#pragma unroll
+          for (int r = 1; r < C_NRED; ++r) { sSum += S.red[0][r][lane]; sCnt += S.red[1][r][lane]; }
+        }
+        binSum.load(sSum); binCnt.load(sCnt);
+      }
+      DecideWork<WaveArrD> wk;
+      wk.ll.load(0.0); wk.lc.load(0.0); wk.ls.load(0.0); wk.u1.load(0.5); wk.u2.load(0.5); wk.val.load(0.0);
+      StepRecord rec; int32_t accepted = 0;
+      const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &rng, &S.prT, tbT, binCnt, binSum, wk, &accepted, &rec, caT);
+      // which candidate (if any) started from the position the generator is at now?
+      const int used = rng.count;
+      if (spec) winner = used == hyp0 ? 1 : ((cand1Exists && used == hyp1) ? 2 : 0);
+      if (lane == 0) __hip_atomic_store(&S.verdict, winner ? winner : 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef S4B_CONTROL_TIMING
+      tk2 = wall_clock64();
+#endif
+      const int cntOut = prT.hwm > hwmNew ? prT.hwm : hwmNew;
+      wave_tree_store(curT, a.var + oT, a.cut + oT, a.left + oT, a.right + oT, a.parent + oT, cntOut, lane);
+      if (lane < cntOut) { a.mu[oT + lane] = mu.mine(); a.cnt[oT + lane] = cnt.r; cT.muOld[lane] = muOld.mine(); cT.insub[lane] = (uint8_t)tbT.insub.r; }
+      if (accepted) {   // the structure cache moved with the tree: keep the global copy current
+        if (lane < cntOut) { a.cna[oT + lane] = (int16_t)curT.na.r; a.cdep[oT + lane] = (int16_t)curT.dep.r; }
+        if (laneIn) { a.cleaf[oT + lane] = (int16_t)caT.leaf.r; a.cpre[oT + lane] = (int16_t)caT.pre.r; a.cpost[oT + lane] = (int16_t)caT.post.r; }
+        if (lane == 0) { a.cnl[t] = caT.nl; a.cni[t] = caT.ni; a.cg[t] = caT.g; a.cgn[t] = caT.gn; a.clogpi[t] = caT.logPi; }
+      }
+      if (lane == 0) {
+        a.hwm[t] = hwmNew; *cT.accepted = accepted;
+        if (a.traceOn) push_trace(a, rec);
+      }
     }
-    if (lane == 0) {
-      a.hwm[t] = hwmNew; *cT.accepted = accepted;
-      if (a.traceOn) push_trace(a, rec);
+    proposer = doPropose && winner == 0;
+    if (!proposer && !doPropose) {   // last tree of the sweep: only the generator goes back
+      rng.close(); S.rng[0].pad = 0;
+      for (int i = lane; i < (int)(sizeof(MTState) / 4); i += 64) ((uint32_t*)a.rng)[i] = ((const uint32_t*)&S.rng[0])[i];
     }
   }
-  S4B_TICK(tk2);
-  if (doPropose) {
-    if (!caN.valid) {   // the tree changed since its lists were built: rebuild memo + lists + log prior, keep them
-      tv_rebuild_cache(curN, m, caN);
-      if (laneIn) { a.cna[oN + lane] = (int16_t)curN.na.r; a.cdep[oN + lane] = (int16_t)curN.dep.r; a.cleaf[oN + lane] = (int16_t)caN.leaf.r;
-                    a.cpre[oN + lane] = (int16_t)caN.pre.r; a.cpost[oN + lane] = (int16_t)caN.post.r; }
-      if (lane == 0) { a.cnl[next] = caN.nl; a.cni[next] = caN.ni; a.cg[next] = caN.g; a.cgn[next] = caN.gn; a.clogpi[next] = caN.logPi; a.cvalid[next] = 1; }
+  if (!proposer) {
+#ifdef S4B_CONTROL_TIMING
+    if (isDecider && lane == 0 && doDecide && doPropose) {
+      S4B_TICK(tk4);
+      atomicAdd((unsigned long long*)&g_dbg[0], (unsigned long long)(tkB - tk0)); atomicAdd((unsigned long long*)&g_dbg[1], (unsigned long long)(tk2 - tkB));
+      atomicAdd((unsigned long long*)&g_dbg[3], (unsigned long long)(tk4 - tk2)); atomicAdd((unsigned long long*)&g_dbg[4], 1ull);
+      atomicAdd((unsigned long long*)&g_dbg[5], (unsigned long long)(tkA - tk0)); atomicAdd((unsigned long long*)&g_dbg[6], (unsigned long long)(tkB - tkA));
+      atomicAdd((unsigned long long*)&g_dbg[7], 1ull);
     }
-    tbN.prop = curN;
-    tbN.binA.r = -1; tbN.binB.r = -1; tbN.insub.r = 0; tbN.list.r = 0;
-    if (propose(curN, hwmN, m, &rng, &s_prN, tbN, caN) != 0 && lane == 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
-    const int cntOut = s_prN.hwm;
+#endif
+    return;
+  }
+
+  // ================================================================ proposal of tree `next` (one call site for all roles)
+  bool rebuilt = false;
+  if (!caN.valid) { tv_rebuild_cache(curN, m, caN); rebuilt = true; }
+  tbN.prop = curN;
+  tbN.binA.r = -1; tbN.binB.r = -1; tbN.insub.r = 0; tbN.list.r = 0;
+  rng.count = 0;
+  const int perr = propose(curN, hwmN, m, &rng, &S.prN[slot], tbN, caN);
+  S4B_TICK(tk3);
+  if (isCand) {
+    spin_until(&S.verdict, 1, a.errFlag);
+    if (__hip_atomic_load(&S.verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 1 + candIdx) return;
+  }
+  if (perr != 0 && lane == 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
+  if (rebuilt) {   // the rebuilt memo + lists + log prior are kept
+    if (laneIn) { a.cna[oN + lane] = (int16_t)curN.na.r; a.cdep[oN + lane] = (int16_t)curN.dep.r; a.cleaf[oN + lane] = (int16_t)caN.leaf.r;
+                  a.cpre[oN + lane] = (int16_t)caN.pre.r; a.cpost[oN + lane] = (int16_t)caN.post.r; }
+    if (lane == 0) { a.cnl[next] = caN.nl; a.cni[next] = caN.ni; a.cg[next] = caN.g; a.cgn[next] = caN.gn; a.clogpi[next] = caN.logPi; a.cvalid[next] = 1; }
+  }
+  {
+    const int cntOut = S4B_UNI(S.prN[slot].hwm);
     wave_tree_store(tbN.prop, cN.pvar, cN.pcut, cN.pleft, cN.pright, cN.pparent, cntOut, lane);
     if (lane < cntOut) { cN.binA[lane] = (int16_t)tbN.binA.r; cN.binB[lane] = (int16_t)tbN.binB.r; cN.insub[lane] = (uint8_t)tbN.insub.r;
                          cN.pna[lane] = (int16_t)tbN.prop.na.r; cN.pdep[lane] = (int16_t)tbN.prop.dep.r; }
-    if (lane == 0) *cN.prop = s_prN;
+    if (lane == 0) *cN.prop = S.prN[slot];
   }
-  S4B_TICK(tk3);
-  // ---- RNG state back to global
-  rng.close();
-  s_rng.pad = 0;
-  for (int i = lane; i < (int)(sizeof(MTState) / 4); i += 64) ((uint32_t*)a.rng)[i] = ((const uint32_t*)&s_rng)[i];
+  // ---- generator state of the surviving stream back to global
+  rng.close(); S.rng[slot].pad = 0;
+  for (int i = lane; i < (int)(sizeof(MTState) / 4); i += 64) ((uint32_t*)a.rng)[i] = ((const uint32_t*)&S.rng[slot])[i];
 #ifdef S4B_CONTROL_TIMING
   { S4B_TICK(tk4);
-    if (lane == 0 && doDecide && doPropose) { atomicAdd((unsigned long long*)&g_dbg[0], (unsigned long long)(tk1 - tk0)); atomicAdd((unsigned long long*)&g_dbg[1], (unsigned long long)(tk2 - tk1));
-      atomicAdd((unsigned long long*)&g_dbg[2], (unsigned long long)(tk3 - tk2)); atomicAdd((unsigned long long*)&g_dbg[3], (unsigned long long)(tk4 - tk3)); atomicAdd((unsigned long long*)&g_dbg[4], 1ull);
-      atomicAdd((unsigned long long*)&g_dbg[5], (unsigned long long)(tkA - tk0)); atomicAdd((unsigned long long*)&g_dbg[6], (unsigned long long)(tkB - tkA)); } }
+    if (lane == 0 && doDecide && doPropose) {
+      if (isDecider) {
+        atomicAdd((unsigned long long*)&g_dbg[0], (unsigned long long)(tkB - tk0)); atomicAdd((unsigned long long*)&g_dbg[1], (unsigned long long)(tk2 - tkB));
+        atomicAdd((unsigned long long*)&g_dbg[2], (unsigned long long)(tk3 - tk2)); atomicAdd((unsigned long long*)&g_dbg[3], (unsigned long long)(tk4 - tk3));
+        atomicAdd((unsigned long long*)&g_dbg[4], 1ull);
+        atomicAdd((unsigned long long*)&g_dbg[5], (unsigned long long)(tkA - tk0)); atomicAdd((unsigned long long*)&g_dbg[6], (unsigned long long)(tkB - tkA));
+      } else {
+        atomicAdd((unsigned long long*)&g_dbg[14], (unsigned long long)(tk3 - tk0)); atomicAdd((unsigned long long*)&g_dbg[15], (unsigned long long)(tk4 - tk0));
+      }
+    } }
 #endif
 }
 
@@ -1161,11 +1235,11 @@ class DevHip {
   void sweep_eager(int thin, bool withLatents) {
     for (int k = 0; k < thin; ++k) {
       // per tree: one fused O(N) kernel (finish tree t-1, statistics of tree t) + one control kernel
-      hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsControl_, stream_, a_, -1, 0); ++launches_;
+      hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, -1, 0); ++launches_;
       for (int t = 0; t < T_; ++t) {
         if (t == 0) hipLaunchKernelGGL(k_tree<false>, dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
         else hipLaunchKernelGGL(k_tree<true>, dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
-        hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsControl_, stream_, a_, t, t + 1 < T_ ? t + 1 : -1);
+        hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, t, t + 1 < T_ ? t + 1 : -1);
         launches_ += 2;
       }
       hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, T_ - 1); ++launches_;
@@ -1178,18 +1252,17 @@ class DevHip {
     std::vector<hipEvent_t> ev((size_t)perSweep * 2 + 4);
     for (auto& e : ev) HIP_OK(hipEventCreate(&e));
     double sum[3] = {0, 0, 0}, cnt[3] = {0, 0, 0};
-    const size_t ldsC = ldsControl_;
     for (int sIdx = 0; sIdx < nSweeps; ++sIdx) {
       size_t e = 0;
       for (int k = 0; k < thin; ++k) {
-        hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsC, stream_, a_, -1, 0); ++launches_;
+        hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, -1, 0); ++launches_;
         for (int t = 0; t < T_; ++t) {
           HIP_OK(hipEventRecord(ev[e++], stream_));
           if (t == 0) hipLaunchKernelGGL(k_tree<false>, dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
           else hipLaunchKernelGGL(k_tree<true>, dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
           HIP_OK(hipEventRecord(ev[e++], stream_));
           HIP_OK(hipEventRecord(ev[e++], stream_));
-          hipLaunchKernelGGL(k_control, dim3(1), dim3(BLOCK), ldsC, stream_, a_, t, t + 1 < T_ ? t + 1 : -1);
+          hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, t, t + 1 < T_ ? t + 1 : -1);
           HIP_OK(hipEventRecord(ev[e++], stream_));
           launches_ += 2;
         }
@@ -1218,7 +1291,7 @@ class DevHip {
     out[6] = ms * 1000.0 / nSweeps;
 #ifdef S4B_CONTROL_TIMING
     { long long h[16]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h)));
-      fprintf(stderr, "DBG k_tree per-WG us: stage %.2f pass %.2f (n=%lld)\n", h[8]/100.0/h[10], h[9]/100.0/h[10], h[10]); fprintf(stderr, "DBG control per-call us: stage %.2f (loads %.2f reduce %.2f) decide %.2f propose %.2f out %.2f n=%lld\n", h[0]/100.0/h[4], h[5]/100.0/h[4], h[6]/100.0/h[4], h[1]/100.0/h[4], h[2]/100.0/h[4], h[3]/100.0/h[4], h[4]); }
+      fprintf(stderr, "DBG k_tree per-WG us: stage %.2f pass %.2f (n=%lld)\n", h[8]/100.0/h[10], h[9]/100.0/h[10], h[10]); fprintf(stderr, "DBG control per-call us: stage %.2f (loads %.2f wait-reduce %.2f) decide %.2f own-propose %.2f out %.2f n=%lld | candidate hit %lld, winner propose-done at %.2f, end at %.2f\n", h[0]/100.0/h[4], h[5]/100.0/h[4], h[6]/100.0/h[4], h[1]/100.0/h[4], h[2]/100.0/h[4], h[3]/100.0/h[4], h[4], h[7], h[7] ? h[14]/100.0/h[7] : 0.0, h[7] ? h[15]/100.0/h[7] : 0.0); }
 #endif
   }
   void test_fits(double* out) {
