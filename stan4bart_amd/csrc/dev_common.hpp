@@ -24,7 +24,12 @@ struct StepScratch {
   double* muOld; Proposal* prop; int32_t* accepted;
   int16_t *pna, *pdep;                // node memo of the proposed tree (pointer path)
   double* work;                       // [6][2 nc] decide() work arrays (pointer path)
+  int16_t* slab;                      // device: the nine int16 tables above are rows of one [SF_COUNT][nc] slab (one base address)
 };
+// row order of the slabs (the individual pointers are views into them)
+enum { SF_VAR = 0, SF_CUT, SF_LEFT, SF_RIGHT, SF_PARENT, SF_NA, SF_DEP, SF_BINA, SF_BINB, SF_COUNT };
+enum { TF_VAR = 0, TF_CUT, TF_LEFT, TF_RIGHT, TF_PARENT, TF_NA, TF_DEP, TF_LEAF, TF_PRE, TF_POST, TF_COUNT };
+enum { TI_HWM = 0, TI_NL, TI_NI, TI_G, TI_GN, TI_VALID, TI_COUNT };
 
 // device-resident state of one chain's BART block (all pointers are device pointers)
 struct BartArrays {
@@ -49,6 +54,9 @@ struct BartArrays {
   // per-tree structure cache, [T][nc] / [T]: node memo (available predictors, depth), leaves in DFS order,
   // internal nodes in pre- and post-order, log tree prior; rebuilt lazily after an accepted move
   int16_t *cna, *cdep, *cleaf, *cpre, *cpost; int32_t *cnl, *cni, *cg, *cgn, *cvalid; double* clogpi;
+  // device: the int16 per-node arrays are rows of treeI16[TF_COUNT][T nc], the int32 per-tree scalars rows of treeI32[TI_COUNT][T]
+  // (the control kernel addresses them from these two bases instead of fetching sixteen kernel-argument pointers)
+  int16_t* treeI16; int32_t* treeI32;
   // updates in flight: two scratch sets, tree t uses set (t & 1) so that the proposal of tree t+1 can be
   // drawn (same lane, same RNG stream position) while the apply pass of tree t still reads its tables
   StepScratch sc[2];

@@ -266,8 +266,7 @@ __global__ __launch_bounds__(BLOCK) void k_tree(BartArrays a, int t) {
   { S4B_TICK(tq2);
     if (APPLY && threadIdx.x == 0) { atomicAdd((unsigned long long*)&g_dbg[8], (unsigned long long)(tq1 - tq0)); atomicAdd((unsigned long long*)&g_dbg[9], (unsigned long long)(tq2 - tq1));
       atomicAdd((unsigned long long*)&g_dbg[10], 1ull);
-      atomicMin((unsigned long long*)&g_dbg[11], (unsigned long long)tq0); atomicMax((unsigned long long*)&g_dbg[12], (unsigned long long)tq2);
-      atomicMax((unsigned long long*)&g_dbg[13], (unsigned long long)tq0); } }
+    } }
 #endif
 }
 
@@ -425,9 +424,48 @@ __device__ __forceinline__ void rng_advance(WaveRng* r, int k) {
   r->mti = total; r->wbase = -64;
 }
 
+// the step's scalars in one gathered load: lane l < 20 holds dword l of the pending Proposal of tree tt, lanes 32.. / 40..
+// the int32 per-tree scalars (row TI_x) of trees tt / tn; a second 8-byte gather brings the two log priors and sigma
+static_assert(sizeof(Proposal) == 80, "gather layout");
+struct StepScalars {
+  int w; int dlo, dhi;
+  __device__ __forceinline__ int i32(int l) const { return __builtin_amdgcn_readlane(w, l); }
+  __device__ __forceinline__ double f64w(int l) const { return __hiloint2double(__builtin_amdgcn_readlane(w, l + 1), __builtin_amdgcn_readlane(w, l)); }
+  __device__ __forceinline__ double f64(int l) const { return __hiloint2double(__builtin_amdgcn_readlane(dhi, l), __builtin_amdgcn_readlane(dlo, l)); }
+  __device__ __forceinline__ void proposal(Proposal& p) const {
+    p.type = i32(0); p.status = i32(1); p.node = i32(2); p.var = i32(3); p.split = i32(4); p.nbA = i32(5); p.nbB = i32(6); p.hwm = i32(7);
+    p.newLeft = i32(8); p.newRight = i32(9); p.pad0 = 0; p.pad1 = 0;
+    p.priorRatio = f64w(12); p.transRatio = f64w(14); p.XLogPi = f64w(16); p.YLogPi = f64w(18);
+  }
+};
+__device__ __forceinline__ void step_scalars_load(StepScalars& g, const BartArrays& a, const Proposal* prop, int tt, int tn, int lane, bool withDoubles) {
+  const int32_t* tS = a.treeI32; const size_t tT = (size_t)a.T;
+  const int32_t* ap = (const int32_t*)prop + (lane < 20 ? lane : 0);
+  const int f = lane & 7;
+  if (lane >= 32 && lane < 48 && f < TI_COUNT) ap = tS + (size_t)f * tT + (lane < 40 ? tt : tn);
+  g.w = (lane < 20 || (lane >= 32 && lane < 48 && f < TI_COUNT)) ? *ap : 0;
+  g.dlo = 0; g.dhi = 0;
+  if (withDoubles) {
+    const double* dp = lane == 0 ? a.clogpi + tt : (lane == 1 ? a.clogpi + tn : &a.scale->sigma);
+    const double d = lane < 3 ? *dp : 0.0;
+    g.dlo = __double2loint(d); g.dhi = __double2hiint(d);
+  }
+}
+// proposal record -> global, one dword per lane
+__device__ __forceinline__ void proposal_store(const Proposal& p, Proposal* dst, int lane) {
+  int w = 0;
+  const int v[20] = {p.type, p.status, p.node, p.var, p.split, p.nbA, p.nbB, p.hwm, p.newLeft, p.newRight, 0, 0,
+                     __double2loint(p.priorRatio), __double2hiint(p.priorRatio), __double2loint(p.transRatio), __double2hiint(p.transRatio),
+                     __double2loint(p.XLogPi), __double2hiint(p.XLogPi), __double2loint(p.YLogPi), __double2hiint(p.YLogPi)};
+#pragma unroll
+  for (int i = 0; i < 20; ++i) w = lane == i ? v[i] : w;
+  if (lane < 20) ((int*)dst)[lane] = w;
+}
+
 __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int next) {
   __shared__ ControlShared S;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: the role branches are scalar branches
   S4B_TICK(tk0);
   if (threadIdx.x == 0) { S.arrived = 0; S.verdict = 0; }
   __syncthreads();
@@ -436,71 +474,119 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
   const StepScratch& cT = a.sc[tt & 1];
   const StepScratch& cN = a.sc[tn & 1];
   const int nc = a.nc;
+  const bool isDecider = wv == 0, isCand = wv == 4 || wv == 5;
+
+  // ================================================================ reducers (waves 1-3, 6, 7)
+  if (!isDecider && !isCand) {
+    if (!doDecide) return;
+    const int redIdx = wv < 4 ? wv - 1 : wv - 3;
+    const int ridx = redIdx * 64 + lane;
+    constexpr int RT = C_NRED * 64;
+    // one hop: first 8 bins (sum, count) of two partials per lane + the scalars that select the path
+    double pv[16], qv[16];
+    {
+      const int b0 = ridx, b1 = ridx + RT;
+      const bool in0 = b0 < a.grid, in1 = b1 < a.grid;
+      const size_t c0 = in0 ? b0 : 0, c1 = in1 ? b1 : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pv[j] = a.partSum[(size_t)j * a.grid + c0]; pv[8 + j] = a.partCnt[(size_t)j * a.grid + c0];
+        qv[j] = a.partSum[(size_t)j * a.grid + c1]; qv[8 + j] = a.partCnt[(size_t)j * a.grid + c1];
+      }
+      StepScalars g; step_scalars_load(g, a, cT.prop, tt, tn, lane, false);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) pv[j] = (in0 ? pv[j] : 0.0) + (in1 ? qv[j] : 0.0);
+      const int prHwm = g.i32(7), nbAll = g.i32(5) + g.i32(6), hwmT = g.i32(32 + TI_HWM), hwmN = g.i32(40 + TI_HWM);
+      int need = prHwm > hwmT ? prHwm : hwmT;
+      if (doPropose && hwmN + 2 > need) need = hwmN + 2;
+      const bool wavePath = need <= 64 && nbAll <= 64 && need <= nc + 2;
+      if (wavePath) {
+        for (int b = ridx + 2 * RT; b < a.grid; b += RT) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { pv[j] += a.partSum[(size_t)j * a.grid + b]; pv[8 + j] += a.partCnt[(size_t)j * a.grid + b]; }
+        }
+        wave_sum_bins<16>(pv, lane);
+        if ((lane & 3) == 0) { const int k = wave_bin_of_lane<16>(lane); S.red[k >> 3][redIdx][k & 7] = pv[0]; }
+        for (int k = 8; k < nbAll; ++k) {   // rare: more than 8 bins
+          double sm = 0.0, c = 0.0;
+          for (int b = ridx; b < a.grid; b += RT) { sm += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
+          sm = wave_sum(sm); c = wave_sum(c);
+          if (lane == 0) { S.red[0][redIdx][k] = sm; S.red[1][redIdx][k] = c; }
+        }
+      } else {   // large tree: totals of every bin to global memory for the sequential path
+        for (int k = redIdx; k < nbAll; k += C_NRED) {
+          double sm = 0.0, c = 0.0;
+          for (int b = lane; b < a.grid; b += 64) { sm += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
+          sm = wave_sum(sm); c = wave_sum(c);
+          if (lane == 0) { a.binSum[k] = sm; a.binCnt[k] = c; }
+        }
+        __threadfence();
+      }
+    }
+    if (lane == 0) __hip_atomic_fetch_add(&S.arrived, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
+
+  // ================================================================ decider (wave 0) and candidates (waves 4, 5)
+  const int candIdx = wv - 4;
+  const int slot = isCand ? 1 + candIdx : 0;
   const size_t oT = (size_t)tt * nc, oN = (size_t)tn * nc;
   const bool laneIn = lane < nc;
   const int li = laneIn ? lane : 0;
-  const bool isDecider = wv == 0, isCand = wv == 4 || wv == 5;
-  const int candIdx = wv - 4;                                  // 0 / 1 for the candidate waves
-  const int redIdx = wv < 4 ? wv - 1 : wv - 3;                 // 0..4 for the reducer waves
-
-  // ---- scalars every role needs (path selection, hypotheses): one hop
-  Proposal prT = *cT.prop;
-  const int hwmT = a.hwm[tt], hwmN = a.hwm[tn];
+  // one base address per slab (dev_common.hpp): field f of tree x = tI + f * ts + x * nc
+  int16_t* const tI = a.treeI16; const size_t ts = (size_t)a.T * nc; int32_t* const tS = a.treeI32; const size_t tT = (size_t)a.T;
+  int16_t* const sT = cT.slab; int16_t* const sN = cN.slab;
+  // ---- one hop: everything this wave needs
+  WaveModel m;
+  static_cast<ModelView&>(m) = a.model;           // overflow pointers (depth >= 64, tables beyond 128 entries) stay global
+  m.scratch = S.scratch[slot];
+  constexpr int MTW = (int)(sizeof(MTState) / 4), MTJ = (MTW + 63) / 64;
+  uint32_t mtw[MTJ];
+#pragma unroll
+  for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; mtw[j] = ((const uint32_t*)a.rng)[i < MTW ? i : 0]; }   // private generator copy
+  m.pg.load(a.model.pgDepth[lane]); m.lpg.load(a.model.logPg[lane]); m.l1pg.load(a.model.log1mPg[lane]);
+  m.li0.load(a.model.logInt[lane < m.logIntLen ? lane : 0]); m.li1.load(a.model.logInt[64 + lane < m.logIntLen ? 64 + lane : 0]);
+  m.nc0 = a.numCuts[lane < a.P ? lane : 0]; m.nc1 = a.numCuts[64 + lane < a.P ? 64 + lane : 0];
+  WaveTree curN; WaveCache caN; WaveTables tbN;
+  curN.var.r = tI[TF_VAR * ts + oN + li]; curN.cut.r = ((uint16_t*)tI)[TF_CUT * ts + oN + li]; curN.left.r = tI[TF_LEFT * ts + oN + li];
+  curN.right.r = tI[TF_RIGHT * ts + oN + li]; curN.parent.r = tI[TF_PARENT * ts + oN + li]; curN.na.r = tI[TF_NA * ts + oN + li];
+  curN.dep.r = tI[TF_DEP * ts + oN + li]; curN.nc = nc < 64 ? nc : 64;
+  caN.leaf.r = tI[TF_LEAF * ts + oN + li]; caN.pre.r = tI[TF_PRE * ts + oN + li]; caN.post.r = tI[TF_POST * ts + oN + li];
+  WaveTree curT; WaveTables tbT; WaveCache caT; WaveArrD mu, muOld; WaveArr<int32_t> cnt;
+  if (isDecider) {
+    curT.var.r = tI[TF_VAR * ts + oT + li]; curT.cut.r = ((uint16_t*)tI)[TF_CUT * ts + oT + li]; curT.left.r = tI[TF_LEFT * ts + oT + li];
+    curT.right.r = tI[TF_RIGHT * ts + oT + li]; curT.parent.r = tI[TF_PARENT * ts + oT + li]; curT.na.r = tI[TF_NA * ts + oT + li];
+    curT.dep.r = tI[TF_DEP * ts + oT + li]; curT.nc = curN.nc;
+    tbT.prop.var.r = sT[SF_VAR * nc + li]; tbT.prop.cut.r = ((uint16_t*)sT)[SF_CUT * nc + li]; tbT.prop.left.r = sT[SF_LEFT * nc + li];
+    tbT.prop.right.r = sT[SF_RIGHT * nc + li]; tbT.prop.parent.r = sT[SF_PARENT * nc + li]; tbT.prop.na.r = sT[SF_NA * nc + li];
+    tbT.prop.dep.r = sT[SF_DEP * nc + li]; tbT.prop.nc = curN.nc;
+    tbT.binA.r = sT[SF_BINA * nc + li]; tbT.binB.r = sT[SF_BINB * nc + li]; tbT.insub.r = cT.insub[li]; tbT.list.r = 0;
+    caT.leaf.r = tI[TF_LEAF * ts + oT + li]; caT.pre.r = tI[TF_PRE * ts + oT + li]; caT.post.r = tI[TF_POST * ts + oT + li];
+    mu.load(a.mu[oT + li]); muOld.load(0.0); cnt.r = a.cnt[oT + li];
+  }
+  StepScalars g; step_scalars_load(g, a, cT.prop, tt, tn, lane, true);
+  // ---- first uses
+  m.li0.load(lane < m.logIntLen ? m.li0.mine() : 0.0); m.li1.load(64 + lane < m.logIntLen ? m.li1.mine() : 0.0);
+  m.nc0 = lane < a.P ? m.nc0 : 0; m.nc1 = 64 + lane < a.P ? m.nc1 : 0;
+  if (!laneIn) { curN.var.r = (int)NODE_FREE; }
+#pragma unroll
+  for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; if (i < MTW) ((uint32_t*)&S.rng[slot])[i] = mtw[j]; }
+  Proposal prT; g.proposal(prT);
+  const int hwmT = g.i32(32 + TI_HWM), hwmN = g.i32(40 + TI_HWM);
+  caN.nl = g.i32(40 + TI_NL); caN.ni = g.i32(40 + TI_NI); caN.g = g.i32(40 + TI_G); caN.gn = g.i32(40 + TI_GN); caN.valid = g.i32(40 + TI_VALID);
+  caN.logPi = g.f64(1);
   int need = 0, nb = 0;
   if (doDecide) { need = prT.hwm > hwmT ? prT.hwm : hwmT; nb = prT.nbA + prT.nbB; }
   if (doPropose && hwmN + 2 > need) need = hwmN + 2;
   const bool wavePath = need <= 64 && nb <= 64 && need <= nc + 2;
-  // generator positions decide(t) can end at (see above); candidate 1 only exists when accepting changes the leaf count
+  // generator positions decide(t) can end at; candidate 1 only exists when accepting changes the number of leaves
   const int drawsAccept = (doDecide && prT.status == 1) ? 1 : 0;
   const int nlNow = prT.nbA;
   const int nlAcc = prT.type == MOVE_BIRTH ? nlNow + 1 : (prT.type == MOVE_DEATH ? nlNow - 1 : nlNow);
   const int hyp0 = drawsAccept + 2 * nlNow, hyp1 = drawsAccept + 2 * nlAcc;
   const bool spec = doDecide && doPropose && next != t && wavePath;
   const bool cand1Exists = spec && drawsAccept == 1 && hyp1 != hyp0;
-
-  // ================================================================ reducers
-  if (!isDecider && !isCand) {
-    if (!doDecide) return;
-    const int ridx = redIdx * 64 + lane;
-    constexpr int RT = C_NRED * 64;
-    if (wavePath) {
-      double pv[16];
-      {
-        const int b0 = ridx, b1 = ridx + RT;
-        const bool in0 = b0 < a.grid, in1 = b1 < a.grid;
-        double qv[16];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          pv[j] = in0 ? a.partSum[(size_t)j * a.grid + b0] : 0.0; pv[8 + j] = in0 ? a.partCnt[(size_t)j * a.grid + b0] : 0.0;
-          qv[j] = in1 ? a.partSum[(size_t)j * a.grid + b1] : 0.0; qv[8 + j] = in1 ? a.partCnt[(size_t)j * a.grid + b1] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) pv[j] += qv[j];
-        for (int b = ridx + 2 * RT; b < a.grid; b += RT) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { pv[j] += a.partSum[(size_t)j * a.grid + b]; pv[8 + j] += a.partCnt[(size_t)j * a.grid + b]; }
-        }
-      }
-      wave_sum_bins<16>(pv, lane);
-      if ((lane & 3) == 0) { const int k = wave_bin_of_lane<16>(lane); S.red[k >> 3][redIdx][k & 7] = pv[0]; }
-      for (int k = 8; k < nb; ++k) {   // rare: more than 8 bins
-        double sm = 0.0, c = 0.0;
-        for (int b = ridx; b < a.grid; b += RT) { sm += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
-        sm = wave_sum(sm); c = wave_sum(c);
-        if (lane == 0) { S.red[0][redIdx][k] = sm; S.red[1][redIdx][k] = c; }
-      }
-    } else {   // large tree: totals of every bin to global memory for the sequential path
-      for (int k = redIdx; k < nb; k += C_NRED) {
-        double sm = 0.0, c = 0.0;
-        for (int b = lane; b < a.grid; b += 64) { sm += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
-        sm = wave_sum(sm); c = wave_sum(c);
-        if (lane == 0) { a.binSum[k] = sm; a.binCnt[k] = c; }
-      }
-      __threadfence();
-    }
-    if (lane == 0) __hip_atomic_fetch_add(&S.arrived, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return;
-  }
+  S4B_TICK(tkA);
   if (!wavePath) {   // large tree: sequential code straight on the global arrays (one lane), no candidates
     if (isCand) return;
     if (doDecide) spin_until(&S.arrived, C_NRED, a.errFlag);
@@ -509,42 +595,7 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
   }
   if (isCand && (!spec || (candIdx == 1 && !cand1Exists))) return;
 
-  // ================================================================ decider and candidates: register-resident state
-  const int slot = isCand ? 1 + candIdx : 0;
-  WaveModel m;
-  static_cast<ModelView&>(m) = a.model;           // overflow pointers (depth >= 64, tables beyond 128 entries) stay global
-  m.scratch = S.scratch[slot];
-  m.pg.load(a.model.pgDepth[lane]); m.lpg.load(a.model.logPg[lane]); m.l1pg.load(a.model.log1mPg[lane]);
-  m.li0.load(lane < m.logIntLen ? a.model.logInt[lane] : 0.0); m.li1.load(64 + lane < m.logIntLen ? a.model.logInt[64 + lane] : 0.0);
-  m.nc0 = lane < a.P ? a.numCuts[lane] : 0; m.nc1 = 64 + lane < a.P ? a.numCuts[64 + lane] : 0;
-  {   // private copy of the generator
-    constexpr int MTW = (int)(sizeof(MTState) / 4), MTJ = (MTW + 63) / 64;
-    uint32_t mtw[MTJ];
-#pragma unroll
-    for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; mtw[j] = i < MTW ? ((const uint32_t*)a.rng)[i] : 0u; }
-#pragma unroll
-    for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; if (i < MTW) ((uint32_t*)&S.rng[slot])[i] = mtw[j]; }
-  }
-  WaveTree curT, curN; WaveTables tbT, tbN; WaveCache caT, caN;
-  WaveArrD mu, muOld; WaveArr<int32_t> cnt;
-  double sigma = 0.0;
-  curN.var.r = a.var[oN + li]; curN.cut.r = a.cut[oN + li]; curN.left.r = a.left[oN + li]; curN.right.r = a.right[oN + li];
-  curN.parent.r = a.parent[oN + li]; curN.na.r = a.cna[oN + li]; curN.dep.r = a.cdep[oN + li]; curN.nc = nc < 64 ? nc : 64;
-  caN.leaf.r = a.cleaf[oN + li]; caN.pre.r = a.cpre[oN + li]; caN.post.r = a.cpost[oN + li];
-  caN.nl = a.cnl[tn]; caN.ni = a.cni[tn]; caN.g = a.cg[tn]; caN.gn = a.cgn[tn]; caN.logPi = a.clogpi[tn]; caN.valid = a.cvalid[tn];
-  if (isDecider) {
-    sigma = a.scale->sigma;
-    curT.var.r = a.var[oT + li]; curT.cut.r = a.cut[oT + li]; curT.left.r = a.left[oT + li]; curT.right.r = a.right[oT + li];
-    curT.parent.r = a.parent[oT + li]; curT.na.r = a.cna[oT + li]; curT.dep.r = a.cdep[oT + li]; curT.nc = curN.nc;
-    tbT.prop.var.r = cT.pvar[li]; tbT.prop.cut.r = cT.pcut[li]; tbT.prop.left.r = cT.pleft[li]; tbT.prop.right.r = cT.pright[li];
-    tbT.prop.parent.r = cT.pparent[li]; tbT.prop.na.r = cT.pna[li]; tbT.prop.dep.r = cT.pdep[li]; tbT.prop.nc = curN.nc;
-    tbT.binA.r = cT.binA[li]; tbT.binB.r = cT.binB[li]; tbT.insub.r = cT.insub[li]; tbT.list.r = 0;
-    caT.leaf.r = a.cleaf[oT + li]; caT.pre.r = a.cpre[oT + li]; caT.post.r = a.cpost[oT + li]; caT.nl = a.cnl[tt]; caT.ni = a.cni[tt];
-    caT.g = a.cg[tt]; caT.gn = a.cgn[tt]; caT.logPi = a.clogpi[tt]; caT.valid = a.cvalid[tt];
-    mu.load(a.mu[oT + li]); muOld.load(0.0); cnt.r = a.cnt[oT + li];
-  }
   WaveRng rng; rng.open(&S.rng[slot]);
-  S4B_TICK(tkA);
   S4B_TICK(tkB);
   S4B_TICK(tk2);
   bool proposer = false;
@@ -554,7 +605,9 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
   } else {
     int winner = 0;
     if (doDecide) {
-      S.prT = prT;
+      caT.nl = g.i32(32 + TI_NL); caT.ni = g.i32(32 + TI_NI); caT.g = g.i32(32 + TI_G); caT.gn = g.i32(32 + TI_GN); caT.valid = g.i32(32 + TI_VALID);
+      caT.logPi = g.f64(0);
+      const double sigma = g.f64(2);
       spin_until(&S.arrived, C_NRED, a.errFlag);
 #ifdef S4B_CONTROL_TIMING
       tkB = wall_clock64();
@@ -572,7 +625,7 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
       DecideWork<WaveArrD> wk;
       wk.ll.load(0.0); wk.lc.load(0.0); wk.ls.load(0.0); wk.u1.load(0.5); wk.u2.load(0.5); wk.val.load(0.0);
       StepRecord rec; int32_t accepted = 0;
-      const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &rng, &S.prT, tbT, binCnt, binSum, wk, &accepted, &rec, caT);
+      const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &rng, &prT, tbT, binCnt, binSum, wk, &accepted, &rec, caT);
       // which candidate (if any) started from the position the generator is at now?
       const int used = rng.count;
       if (spec) winner = used == hyp0 ? 1 : ((cand1Exists && used == hyp1) ? 2 : 0);
@@ -581,22 +634,26 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
       tk2 = wall_clock64();
 #endif
       const int cntOut = prT.hwm > hwmNew ? prT.hwm : hwmNew;
-      wave_tree_store(curT, a.var + oT, a.cut + oT, a.left + oT, a.right + oT, a.parent + oT, cntOut, lane);
+      wave_tree_store(curT, tI + TF_VAR * ts + oT, (uint16_t*)(tI + TF_CUT * ts + oT), tI + TF_LEFT * ts + oT, tI + TF_RIGHT * ts + oT,
+                      tI + TF_PARENT * ts + oT, cntOut, lane);
       if (lane < cntOut) { a.mu[oT + lane] = mu.mine(); a.cnt[oT + lane] = cnt.r; cT.muOld[lane] = muOld.mine(); cT.insub[lane] = (uint8_t)tbT.insub.r; }
       if (accepted) {   // the structure cache moved with the tree: keep the global copy current
-        if (lane < cntOut) { a.cna[oT + lane] = (int16_t)curT.na.r; a.cdep[oT + lane] = (int16_t)curT.dep.r; }
-        if (laneIn) { a.cleaf[oT + lane] = (int16_t)caT.leaf.r; a.cpre[oT + lane] = (int16_t)caT.pre.r; a.cpost[oT + lane] = (int16_t)caT.post.r; }
-        if (lane == 0) { a.cnl[t] = caT.nl; a.cni[t] = caT.ni; a.cg[t] = caT.g; a.cgn[t] = caT.gn; a.clogpi[t] = caT.logPi; }
+        if (lane < cntOut) { tI[TF_NA * ts + oT + lane] = (int16_t)curT.na.r; tI[TF_DEP * ts + oT + lane] = (int16_t)curT.dep.r; }
+        if (laneIn) { tI[TF_LEAF * ts + oT + lane] = (int16_t)caT.leaf.r; tI[TF_PRE * ts + oT + lane] = (int16_t)caT.pre.r; tI[TF_POST * ts + oT + lane] = (int16_t)caT.post.r; }
+        if (lane == 0) { tS[TI_NL * tT + t] = caT.nl; tS[TI_NI * tT + t] = caT.ni; tS[TI_G * tT + t] = caT.g; tS[TI_GN * tT + t] = caT.gn; a.clogpi[t] = caT.logPi; }
       }
       if (lane == 0) {
-        a.hwm[t] = hwmNew; *cT.accepted = accepted;
+        tS[TI_HWM * tT + t] = hwmNew; *cT.accepted = accepted;
         if (a.traceOn) push_trace(a, rec);
       }
     }
     proposer = doPropose && winner == 0;
-    if (!proposer && !doPropose) {   // last tree of the sweep: only the generator goes back
+    if (!doPropose) {   // last tree of the sweep: only the generator goes back
       rng.close(); S.rng[0].pad = 0;
-      for (int i = lane; i < (int)(sizeof(MTState) / 4); i += 64) ((uint32_t*)a.rng)[i] = ((const uint32_t*)&S.rng[0])[i];
+#pragma unroll
+      for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; mtw[j] = ((const uint32_t*)&S.rng[0])[i < MTW ? i : 0]; }
+#pragma unroll
+      for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; if (i < MTW) ((uint32_t*)a.rng)[i] = mtw[j]; }
     }
   }
   if (!proposer) {
@@ -617,8 +674,8 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
   if (!caN.valid) { tv_rebuild_cache(curN, m, caN); rebuilt = true; }
   tbN.prop = curN;
   tbN.binA.r = -1; tbN.binB.r = -1; tbN.insub.r = 0; tbN.list.r = 0;
-  rng.count = 0;
-  const int perr = propose(curN, hwmN, m, &rng, &S.prN[slot], tbN, caN);
+  Proposal prN;
+  const int perr = propose(curN, hwmN, m, &rng, &prN, tbN, caN);
   S4B_TICK(tk3);
   if (isCand) {
     spin_until(&S.verdict, 1, a.errFlag);
@@ -626,20 +683,23 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
   }
   if (perr != 0 && lane == 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
   if (rebuilt) {   // the rebuilt memo + lists + log prior are kept
-    if (laneIn) { a.cna[oN + lane] = (int16_t)curN.na.r; a.cdep[oN + lane] = (int16_t)curN.dep.r; a.cleaf[oN + lane] = (int16_t)caN.leaf.r;
-                  a.cpre[oN + lane] = (int16_t)caN.pre.r; a.cpost[oN + lane] = (int16_t)caN.post.r; }
-    if (lane == 0) { a.cnl[next] = caN.nl; a.cni[next] = caN.ni; a.cg[next] = caN.g; a.cgn[next] = caN.gn; a.clogpi[next] = caN.logPi; a.cvalid[next] = 1; }
+    if (laneIn) { tI[TF_NA * ts + oN + lane] = (int16_t)curN.na.r; tI[TF_DEP * ts + oN + lane] = (int16_t)curN.dep.r; tI[TF_LEAF * ts + oN + lane] = (int16_t)caN.leaf.r;
+                  tI[TF_PRE * ts + oN + lane] = (int16_t)caN.pre.r; tI[TF_POST * ts + oN + lane] = (int16_t)caN.post.r; }
+    if (lane == 0) { tS[TI_NL * tT + next] = caN.nl; tS[TI_NI * tT + next] = caN.ni; tS[TI_G * tT + next] = caN.g; tS[TI_GN * tT + next] = caN.gn; a.clogpi[next] = caN.logPi; tS[TI_VALID * tT + next] = 1; }
   }
   {
-    const int cntOut = S4B_UNI(S.prN[slot].hwm);
-    wave_tree_store(tbN.prop, cN.pvar, cN.pcut, cN.pleft, cN.pright, cN.pparent, cntOut, lane);
-    if (lane < cntOut) { cN.binA[lane] = (int16_t)tbN.binA.r; cN.binB[lane] = (int16_t)tbN.binB.r; cN.insub[lane] = (uint8_t)tbN.insub.r;
-                         cN.pna[lane] = (int16_t)tbN.prop.na.r; cN.pdep[lane] = (int16_t)tbN.prop.dep.r; }
-    if (lane == 0) *cN.prop = S.prN[slot];
+    const int cntOut = prN.hwm;
+    wave_tree_store(tbN.prop, sN + SF_VAR * nc, (uint16_t*)(sN + SF_CUT * nc), sN + SF_LEFT * nc, sN + SF_RIGHT * nc, sN + SF_PARENT * nc, cntOut, lane);
+    if (lane < cntOut) { sN[SF_BINA * nc + lane] = (int16_t)tbN.binA.r; sN[SF_BINB * nc + lane] = (int16_t)tbN.binB.r; cN.insub[lane] = (uint8_t)tbN.insub.r;
+                         sN[SF_NA * nc + lane] = (int16_t)tbN.prop.na.r; sN[SF_DEP * nc + lane] = (int16_t)tbN.prop.dep.r; }
+    proposal_store(prN, cN.prop, lane);
   }
   // ---- generator state of the surviving stream back to global
   rng.close(); S.rng[slot].pad = 0;
-  for (int i = lane; i < (int)(sizeof(MTState) / 4); i += 64) ((uint32_t*)a.rng)[i] = ((const uint32_t*)&S.rng[slot])[i];
+#pragma unroll
+  for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; mtw[j] = ((const uint32_t*)&S.rng[slot])[i < MTW ? i : 0]; }
+#pragma unroll
+  for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; if (i < MTW) ((uint32_t*)a.rng)[i] = mtw[j]; }
 #ifdef S4B_CONTROL_TIMING
   { S4B_TICK(tk4);
     if (lane == 0 && doDecide && doPropose) {
@@ -1066,11 +1126,13 @@ class DevHip {
     a.leaf = alloc<uint16_t>((size_t)T_ * a.npad); HIP_OK(hipMemsetAsync(a.leaf, 0, (size_t)T_ * a.npad * 2, stream_));
     // ---- trees
     const size_t m = (size_t)T_ * nc_;
-    a.var = alloc<int16_t>(m); a.left = alloc<int16_t>(m); a.right = alloc<int16_t>(m); a.parent = alloc<int16_t>(m); a.cut = alloc<uint16_t>(m);
-    a.mu = alloc<double>(m); a.cnt = alloc<int32_t>(m); a.hwm = alloc<int32_t>((size_t)T_);
-    a.cna = zalloc<int16_t>(m); a.cdep = zalloc<int16_t>(m); a.cleaf = zalloc<int16_t>(m); a.cpre = zalloc<int16_t>(m); a.cpost = zalloc<int16_t>(m);
-    a.cnl = zalloc<int32_t>((size_t)T_); a.cni = zalloc<int32_t>((size_t)T_); a.cg = zalloc<int32_t>((size_t)T_); a.cgn = zalloc<int32_t>((size_t)T_);
-    a.cvalid = zalloc<int32_t>((size_t)T_); a.clogpi = zalloc<double>((size_t)T_);
+    a.treeI16 = zalloc<int16_t>((size_t)TF_COUNT * m); a.treeI32 = zalloc<int32_t>((size_t)TI_COUNT * T_);
+    a.var = a.treeI16 + TF_VAR * m; a.cut = (uint16_t*)(a.treeI16 + TF_CUT * m); a.left = a.treeI16 + TF_LEFT * m; a.right = a.treeI16 + TF_RIGHT * m;
+    a.parent = a.treeI16 + TF_PARENT * m; a.cna = a.treeI16 + TF_NA * m; a.cdep = a.treeI16 + TF_DEP * m; a.cleaf = a.treeI16 + TF_LEAF * m;
+    a.cpre = a.treeI16 + TF_PRE * m; a.cpost = a.treeI16 + TF_POST * m;
+    a.hwm = a.treeI32 + TI_HWM * T_; a.cnl = a.treeI32 + TI_NL * T_; a.cni = a.treeI32 + TI_NI * T_; a.cg = a.treeI32 + TI_G * T_;
+    a.cgn = a.treeI32 + TI_GN * T_; a.cvalid = a.treeI32 + TI_VALID * T_;
+    a.mu = alloc<double>(m); a.cnt = alloc<int32_t>(m); a.clogpi = zalloc<double>((size_t)T_);
     {
       std::vector<int16_t> var(m, NODE_FREE), neg(m, -1); std::vector<int32_t> hwm((size_t)T_, 1);
       for (int t = 0; t < T_; ++t) var[(size_t)t * nc_] = NODE_LEAF;
@@ -1081,10 +1143,12 @@ class DevHip {
     }
     for (int s = 0; s < 2; ++s) {
       StepScratch& c = a.sc[s];
-      c.pvar = zalloc<int16_t>(nc_); c.pleft = zalloc<int16_t>(nc_); c.pright = zalloc<int16_t>(nc_); c.pparent = zalloc<int16_t>(nc_); c.pcut = zalloc<uint16_t>(nc_);
-      c.binA = zalloc<int16_t>(nc_); c.binB = zalloc<int16_t>(nc_); c.list = zalloc<int16_t>(nc_); c.insub = zalloc<uint8_t>(nc_);
+      c.slab = zalloc<int16_t>((size_t)SF_COUNT * nc_);
+      c.pvar = c.slab + SF_VAR * nc_; c.pcut = (uint16_t*)(c.slab + SF_CUT * nc_); c.pleft = c.slab + SF_LEFT * nc_; c.pright = c.slab + SF_RIGHT * nc_;
+      c.pparent = c.slab + SF_PARENT * nc_; c.pna = c.slab + SF_NA * nc_; c.pdep = c.slab + SF_DEP * nc_; c.binA = c.slab + SF_BINA * nc_; c.binB = c.slab + SF_BINB * nc_;
+      c.list = zalloc<int16_t>(nc_); c.insub = zalloc<uint8_t>(nc_);
       c.muOld = zalloc<double>(nc_); c.prop = zalloc<Proposal>(1); c.accepted = zalloc<int32_t>(1);
-      c.pna = zalloc<int16_t>(nc_); c.pdep = zalloc<int16_t>(nc_); c.work = zalloc<double>((size_t)12 * nc_);
+      c.work = zalloc<double>((size_t)12 * nc_);
     }
     a.partCnt = zalloc<double>((size_t)a.binCap * a.grid); a.partSum = zalloc<double>((size_t)a.binCap * a.grid);
     a.binCnt = zalloc<double>((size_t)a.binCap); a.binSum = zalloc<double>((size_t)a.binCap);
@@ -1291,7 +1355,7 @@ class DevHip {
     out[6] = ms * 1000.0 / nSweeps;
 #ifdef S4B_CONTROL_TIMING
     { long long h[16]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h)));
-      fprintf(stderr, "DBG k_tree per-WG us: stage %.2f pass %.2f (n=%lld)\n", h[8]/100.0/h[10], h[9]/100.0/h[10], h[10]); fprintf(stderr, "DBG control per-call us: stage %.2f (loads %.2f wait-reduce %.2f) decide %.2f own-propose %.2f out %.2f n=%lld | candidate hit %lld, winner propose-done at %.2f, end at %.2f\n", h[0]/100.0/h[4], h[5]/100.0/h[4], h[6]/100.0/h[4], h[1]/100.0/h[4], h[2]/100.0/h[4], h[3]/100.0/h[4], h[4], h[7], h[7] ? h[14]/100.0/h[7] : 0.0, h[7] ? h[15]/100.0/h[7] : 0.0); }
+      fprintf(stderr, "DBG k_tree per-WG us: stage %.2f pass %.2f (n=%lld)\n", h[8]/100.0/h[10], h[9]/100.0/h[10], h[10]);       fprintf(stderr, "DBG control per-call us: stage %.2f (loads %.2f wait-reduce %.2f) decide %.2f own-propose %.2f out %.2f n=%lld | candidate hit %lld, winner propose-done at %.2f, end at %.2f\n", h[0]/100.0/h[4], h[5]/100.0/h[4], h[6]/100.0/h[4], h[1]/100.0/h[4], h[2]/100.0/h[4], h[3]/100.0/h[4], h[4], h[7], h[7] ? h[14]/100.0/h[7] : 0.0, h[7] ? h[15]/100.0/h[7] : 0.0); }
 #endif
   }
   void test_fits(double* out) {
