@@ -84,10 +84,12 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 #ifdef S4B_CONTROL_TIMING
-__device__ long long g_dbg[16];
+__device__ long long g_dbg[32];
 #define S4B_TICK(x) long long x = wall_clock64()
+#define S4B_PTICK(x) __builtin_amdgcn_sched_barrier(0); long long x = wall_clock64(); __builtin_amdgcn_sched_barrier(0)
 #else
 #define S4B_TICK(x)
+#define S4B_PTICK(x)
 #endif
 // ------------------------------------------------------------------------------------------------
 // k_tree: the O(N) kernel of one tree update.  One pass over the observations:
@@ -394,14 +396,14 @@ __device__ __forceinline__ int mv_num_cuts(const WaveModel& m, int v) {
 
 // Workgroup of 8 waves with fixed roles, tied together by two LDS hand-shakes (no workgroup barrier after start-up):
 //   wave 0        decide(t): waits for the bin totals, accept/reject, leaf draws, writes tree t, names the winner
-//   waves 4, 5    candidates: draw the proposal of tree `next` from the generator position decide(t) will leave behind —
+//   waves 1, 2    candidates (waves are dealt round-robin to the 4 SIMDs: the three long-running roles sit on three SIMDs): draw the proposal of tree `next` from the generator position decide(t) will leave behind —
 //                 that position is known up to one bit before the statistics arrive: decide consumes one uniform for the
 //                 accept test plus two per leaf of the tree it ends with, i.e. d + 2 nl (reject) or d + 2 nl' (accept).
 //                 Each candidate advances a private copy of the generator by its hypothesis and runs propose() while
 //                 wave 0 is still waiting / deciding; the one whose hypothesis matches the draws actually consumed
 //                 publishes its tables and generator state.  A leaf without observations (no draw) breaks both
 //                 hypotheses: then wave 0 proposes itself, as it does at the start of a sweep.
-//   waves 1-3,6,7 reducers: per-workgroup partials -> bin totals (fixed order)
+//   waves 3-7     reducers: per-workgroup partials -> bin totals (fixed order)
 constexpr int CBLOCK = 512;
 constexpr int C_NRED = 5;
 struct ControlShared {
@@ -410,6 +412,7 @@ struct ControlShared {
   double red[2][C_NRED][64];             // [sum | count][reducer][bin]
   Proposal prT, prN[3];
   int arrived, verdict;
+  long long tPost, tStart0;
 };
 __device__ __forceinline__ void spin_until(int* flag, int target, int32_t* errFlag) {
   int guard = 0;
@@ -474,12 +477,12 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
   const StepScratch& cT = a.sc[tt & 1];
   const StepScratch& cN = a.sc[tn & 1];
   const int nc = a.nc;
-  const bool isDecider = wv == 0, isCand = wv == 4 || wv == 5;
+  const bool isDecider = wv == 0, isCand = wv == 1 || wv == 2;
 
-  // ================================================================ reducers (waves 1-3, 6, 7)
+  // ================================================================ reducers (waves 3-7)
   if (!isDecider && !isCand) {
     if (!doDecide) return;
-    const int redIdx = wv < 4 ? wv - 1 : wv - 3;
+    const int redIdx = wv - 3;
     const int ridx = redIdx * 64 + lane;
     constexpr int RT = C_NRED * 64;
     // one hop: first 8 bins (sum, count) of two partials per lane + the scalars that select the path
@@ -527,8 +530,8 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
     return;
   }
 
-  // ================================================================ decider (wave 0) and candidates (waves 4, 5)
-  const int candIdx = wv - 4;
+  // ================================================================ decider (wave 0) and candidates (waves 1, 2)
+  const int candIdx = wv - 1;
   const int slot = isCand ? 1 + candIdx : 0;
   const size_t oT = (size_t)tt * nc, oN = (size_t)tn * nc;
   const bool laneIn = lane < nc;
@@ -596,12 +599,14 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
   if (isCand && (!spec || (candIdx == 1 && !cand1Exists))) return;
 
   WaveRng rng; rng.open(&S.rng[slot]);
+  S4B_PTICK(tc1);
   S4B_TICK(tkB);
   S4B_TICK(tk2);
   bool proposer = false;
   if (isCand) {
     rng_advance(&rng, candIdx == 0 ? hyp0 : hyp1);
     proposer = true;
+    rng.count = 0;
   } else {
     int winner = 0;
     if (doDecide) {
@@ -625,11 +630,17 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
       DecideWork<WaveArrD> wk;
       wk.ll.load(0.0); wk.lc.load(0.0); wk.ls.load(0.0); wk.u1.load(0.5); wk.u2.load(0.5); wk.val.load(0.0);
       StepRecord rec; int32_t accepted = 0;
-      const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &rng, &prT, tbT, binCnt, binSum, wk, &accepted, &rec, caT);
-      // which candidate (if any) started from the position the generator is at now?
-      const int used = rng.count;
-      if (spec) winner = used == hyp0 ? 1 : ((cand1Exists && used == hyp1) ? 2 : 0);
-      if (lane == 0) __hip_atomic_store(&S.verdict, winner ? winner : 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // as soon as the step's last random number is drawn: which candidate (if any) started from the position the
+      // generator is at now?  (posted before the leaf arithmetic so that the winner publishes meanwhile)
+      auto post = [&]() {
+        const int used = rng.count;
+        if (spec) winner = used == hyp0 ? 1 : ((cand1Exists && used == hyp1) ? 2 : 0);
+        if (lane == 0) __hip_atomic_store(&S.verdict, winner ? winner : 3, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef S4B_CONTROL_TIMING
+        if (lane == 0) { S.tPost = wall_clock64(); S.tStart0 = tk0; }
+#endif
+      };
+      const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &rng, &prT, tbT, binCnt, binSum, wk, &accepted, &rec, caT, post);
 #ifdef S4B_CONTROL_TIMING
       tk2 = wall_clock64();
 #endif
@@ -671,16 +682,20 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
 
   // ================================================================ proposal of tree `next` (one call site for all roles)
   bool rebuilt = false;
+  S4B_PTICK(tc2);
   if (!caN.valid) { tv_rebuild_cache(curN, m, caN); rebuilt = true; }
+  S4B_PTICK(tc3);
   tbN.prop = curN;
   tbN.binA.r = -1; tbN.binB.r = -1; tbN.insub.r = 0; tbN.list.r = 0;
   Proposal prN;
   const int perr = propose(curN, hwmN, m, &rng, &prN, tbN, caN);
+  S4B_PTICK(tc4);
   S4B_TICK(tk3);
   if (isCand) {
     spin_until(&S.verdict, 1, a.errFlag);
     if (__hip_atomic_load(&S.verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 1 + candIdx) return;
   }
+  S4B_PTICK(tc5);
   if (perr != 0 && lane == 0) *a.errFlag |= S4B_ERR_NODE_CAPACITY;
   if (rebuilt) {   // the rebuilt memo + lists + log prior are kept
     if (laneIn) { tI[TF_NA * ts + oN + lane] = (int16_t)curN.na.r; tI[TF_DEP * ts + oN + lane] = (int16_t)curN.dep.r; tI[TF_LEAF * ts + oN + lane] = (int16_t)caN.leaf.r;
@@ -710,6 +725,11 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
         atomicAdd((unsigned long long*)&g_dbg[5], (unsigned long long)(tkA - tk0)); atomicAdd((unsigned long long*)&g_dbg[6], (unsigned long long)(tkB - tkA));
       } else {
         atomicAdd((unsigned long long*)&g_dbg[14], (unsigned long long)(tk3 - tk0)); atomicAdd((unsigned long long*)&g_dbg[15], (unsigned long long)(tk4 - tk0));
+        atomicAdd((unsigned long long*)&g_dbg[16], (unsigned long long)(tc1 - tk0)); atomicAdd((unsigned long long*)&g_dbg[17], (unsigned long long)(tc2 - tc1));
+        atomicAdd((unsigned long long*)&g_dbg[18], (unsigned long long)(tc3 - tc2)); atomicAdd((unsigned long long*)&g_dbg[19], (unsigned long long)(tc4 - tc3));
+        atomicAdd((unsigned long long*)&g_dbg[20], (unsigned long long)(tc5 - tc4)); atomicAdd((unsigned long long*)&g_dbg[21], (unsigned long long)(tk4 - tc5));
+        atomicAdd((unsigned long long*)&g_dbg[22], (unsigned long long)rng.count);
+        atomicAdd((unsigned long long*)&g_dbg[23], (unsigned long long)(tc4 - S.tPost + 100000)); atomicAdd((unsigned long long*)&g_dbg[24], (unsigned long long)(tk0 - S.tStart0 + 100000));
       }
     } }
 #endif
@@ -1354,7 +1374,9 @@ class DevHip {
     float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_));
     out[6] = ms * 1000.0 / nSweeps;
 #ifdef S4B_CONTROL_TIMING
-    { long long h[16]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h)));
+    { long long h[32]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h)));
+      if (h[7]) fprintf(stderr, "DBG candidate timeline us: loads %.2f advance %.2f rebuild %.2f propose %.2f wait-verdict %.2f stores %.2f | draws/propose %.2f\n", h[16]/100.0/h[7], h[17]/100.0/h[7], h[18]/100.0/h[7], h[19]/100.0/h[7], h[20]/100.0/h[7], h[21]/100.0/h[7], (double)h[22]/h[7]);
+      if (h[7]) fprintf(stderr, "DBG candidate reached the verdict wait %.2f us after wave 0 posted it; candidate wave started %.2f us after wave 0\n", (h[23]/(double)h[7] - 100000)/100.0, (h[24]/(double)h[7] - 100000)/100.0);
       fprintf(stderr, "DBG k_tree per-WG us: stage %.2f pass %.2f (n=%lld)\n", h[8]/100.0/h[10], h[9]/100.0/h[10], h[10]);       fprintf(stderr, "DBG control per-call us: stage %.2f (loads %.2f wait-reduce %.2f) decide %.2f own-propose %.2f out %.2f n=%lld | candidate hit %lld, winner propose-done at %.2f, end at %.2f\n", h[0]/100.0/h[4], h[5]/100.0/h[4], h[6]/100.0/h[4], h[1]/100.0/h[4], h[2]/100.0/h[4], h[3]/100.0/h[4], h[4], h[7], h[7] ? h[14]/100.0/h[7] : 0.0, h[7] ? h[15]/100.0/h[7] : 0.0); }
 #endif
   }
@@ -1399,7 +1421,20 @@ class DevHip {
   void sync() { HIP_OK(hipStreamSynchronize(stream_)); }
 
  private:
-  template <class T> T* alloc(size_t count) { void* p = nullptr; HIP_OK(hipMalloc(&p, std::max<size_t>(16, count * sizeof(T)))); allocs_.push_back(p); return (T*)p; }
+  // small arrays (everything the control kernel touches) are carved from one arena so that they share a few pages;
+  // observation-length arrays get their own allocation
+  template <class T> T* alloc(size_t count) {
+    const size_t bytes = std::max<size_t>(16, count * sizeof(T));
+    if (bytes <= ((size_t)2 << 20)) {
+      const size_t need = (bytes + 255) / 256 * 256;
+      if (!arena_ || arenaUsed_ + need > arenaSize_) {
+        arenaSize_ = (size_t)32 << 20; arenaUsed_ = 0;
+        void* q = nullptr; HIP_OK(hipMalloc(&q, arenaSize_)); allocs_.push_back(q); arena_ = (char*)q;
+      }
+      T* r = (T*)(arena_ + arenaUsed_); arenaUsed_ += need; return r;
+    }
+    void* p = nullptr; HIP_OK(hipMalloc(&p, bytes)); allocs_.push_back(p); return (T*)p;
+  }
   template <class T> T* zalloc(size_t count) { T* p = alloc<T>(count); HIP_OK(hipMemsetAsync(p, 0, std::max<size_t>(16, count * sizeof(T)), stream_)); return p; }
   template <class T> void upload(T* dst, const T* src, size_t count) { if (count) HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, stream_)); }
   template <class T> void download(T* dst, const T* src, size_t count) { if (count) HIP_OK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, stream_)); }
@@ -1461,6 +1496,7 @@ class DevHip {
   hipGraph_t graph_ = nullptr; hipGraphExec_t graphExec_ = nullptr; int graphTrace_ = -1; bool useGraph_ = true;
   BartArrays a_; StanArrays s_;
   std::vector<void*> allocs_;
+  char* arena_ = nullptr; size_t arenaSize_ = 0, arenaUsed_ = 0;
   double* pinned_ = nullptr; double* testOut_ = nullptr;
   int64_t launches_ = 0;
 };

@@ -578,10 +578,12 @@ S4B_HD inline void leaves_draw(const AF64& lc, const AF64& ls, const AF64& u1, c
 template <class AF64>
 struct DecideWork { AF64 ll, lc, ls, u1, u2, val; };
 
-template <class TR, class TBL, class AF64, class AI32, class ABIN, class CA, class MV, class RNG>
+struct NoHook { S4B_HD void operator()() const {} };
+// `drawsDone` is called once the last random number of the step has been consumed (before the batched leaf arithmetic)
+template <class TR, class TBL, class AF64, class AI32, class ABIN, class CA, class MV, class RNG, class HOOK = NoHook>
 S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, const MV& m, double sigma, RNG* rng,
                          const Proposal* pr, TBL& tb, const ABIN& binCnt, const ABIN& binSum, DecideWork<AF64>& wk,
-                         int32_t* accepted, StepRecord* rec, CA& ca) {
+                         int32_t* accepted, StepRecord* rec, CA& ca, const HOOK& drawsDone = HOOK()) {
   TR& pt = tb.prop;
   sigma = S4B_UNI(sigma);
   const double sigma2 = sigma * sigma;
@@ -678,6 +680,7 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
     wk.lc.set(i, lc); wk.ls.set(i, ls);
     if (lc != 0.0) { wk.u1.set(i, r_unif(rng)); wk.u2.set(i, r_unif(rng)); }
   }
+  drawsDone();
   leaves_draw(wk.lc, wk.ls, wk.u1, wk.u2, nl, sigma2, m.leafPrec, wk.val);
   for (int i = 0; i < nl; ++i) { int n = ca.leaf.get(i); cnt.set(n, (int32_t)wk.lc.get(i)); mu.set(n, wk.val.get(i)); }
   if (rec) { rec->type = prType; rec->status = prStatus == 1 ? acc : -1; rec->var = pr->var; rec->split = pr->split; rec->numLeaves = nl; }
