@@ -84,7 +84,7 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 #ifdef S4B_CONTROL_TIMING
-__device__ long long g_dbg[32];
+__device__ long long g_dbg[40];
 #define S4B_TICK(x) long long x = wall_clock64()
 #define S4B_PTICK(x) __builtin_amdgcn_sched_barrier(0); long long x = wall_clock64(); __builtin_amdgcn_sched_barrier(0)
 #else
@@ -729,6 +729,7 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
         atomicAdd((unsigned long long*)&g_dbg[18], (unsigned long long)(tc3 - tc2)); atomicAdd((unsigned long long*)&g_dbg[19], (unsigned long long)(tc4 - tc3));
         atomicAdd((unsigned long long*)&g_dbg[20], (unsigned long long)(tc5 - tc4)); atomicAdd((unsigned long long*)&g_dbg[21], (unsigned long long)(tk4 - tc5));
         atomicAdd((unsigned long long*)&g_dbg[22], (unsigned long long)rng.count);
+        { const int ty = prN.type & 3; atomicAdd((unsigned long long*)&g_dbg[25 + ty], (unsigned long long)(tc4 - tc3)); atomicAdd((unsigned long long*)&g_dbg[32 + ty], 1ull); }
         atomicAdd((unsigned long long*)&g_dbg[23], (unsigned long long)(tc4 - S.tPost + 100000)); atomicAdd((unsigned long long*)&g_dbg[24], (unsigned long long)(tk0 - S.tStart0 + 100000));
       }
     } }
@@ -1374,7 +1375,9 @@ class DevHip {
     float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_));
     out[6] = ms * 1000.0 / nSweeps;
 #ifdef S4B_CONTROL_TIMING
-    { long long h[32]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h)));
+    { long long h[40]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h)));
+      fprintf(stderr, "DBG winner propose us by move type (count): birth %.2f (%lld) death %.2f (%lld) swap %.2f (%lld) change %.2f (%lld)\n",
+              h[32] ? h[25]/100.0/h[32] : 0.0, h[32], h[33] ? h[26]/100.0/h[33] : 0.0, h[33], h[34] ? h[27]/100.0/h[34] : 0.0, h[34], h[35] ? h[28]/100.0/h[35] : 0.0, h[35]);
       if (h[7]) fprintf(stderr, "DBG candidate timeline us: loads %.2f advance %.2f rebuild %.2f propose %.2f wait-verdict %.2f stores %.2f | draws/propose %.2f\n", h[16]/100.0/h[7], h[17]/100.0/h[7], h[18]/100.0/h[7], h[19]/100.0/h[7], h[20]/100.0/h[7], h[21]/100.0/h[7], (double)h[22]/h[7]);
       if (h[7]) fprintf(stderr, "DBG candidate reached the verdict wait %.2f us after wave 0 posted it; candidate wave started %.2f us after wave 0\n", (h[23]/(double)h[7] - 100000)/100.0, (h[24]/(double)h[7] - 100000)/100.0);
       fprintf(stderr, "DBG k_tree per-WG us: stage %.2f pass %.2f (n=%lld)\n", h[8]/100.0/h[10], h[9]/100.0/h[10], h[10]);       fprintf(stderr, "DBG control per-call us: stage %.2f (loads %.2f wait-reduce %.2f) decide %.2f own-propose %.2f out %.2f n=%lld | candidate hit %lld, winner propose-done at %.2f, end at %.2f\n", h[0]/100.0/h[4], h[5]/100.0/h[4], h[6]/100.0/h[4], h[1]/100.0/h[4], h[2]/100.0/h[4], h[3]/100.0/h[4], h[4], h[7], h[7] ? h[14]/100.0/h[7] : 0.0, h[7] ? h[15]/100.0/h[7] : 0.0); }

@@ -388,6 +388,70 @@ template <class TR, class MV> S4B_HD inline bool tv_rules_valid(const TR& t, con
   return true;
 }
 
+
+// smallest / largest cut on predictor v among the internal nodes of the left and of the right subtree of nd (one walk)
+template <class TR> S4B_HD inline void tv_min_max_split_sides(const TR& t, int nd, int v, int& lmn, int& lmx, int& rmn, int& rmx) {
+  const int rc = t.right.get(nd);
+  bool right = false;
+  int node, k; Walker<TR> w(t, nd);
+  while (w.next(node, k)) {
+    if (k == 2 || node == nd) continue;
+    if (node == rc) right = true;
+    if (k == 1 && t.var.get(node) == v) {
+      const int s = (int)t.cut.get(node);
+      if (right) { rmn = s < rmn ? s : rmn; rmx = s > rmx ? s : rmx; } else { lmn = s < lmn ? s : lmn; lmx = s > lmx ? s : lmx; }
+    }
+  }
+}
+
+// swap / change proposals: `pt` differs from `cur` only in rules inside the subtree under nd (same shape).  Walks it
+// once and, in walk order, (a) optionally verifies every rule of pt against its interval (returns false at the first
+// violation), (b) fills pt's memo below nd (tv_fill_info_node arithmetic, the interval of each internal node computed
+// once), (c) accumulates the own log-prior terms of cur and of pt (tv_log_prior_own arithmetic and order),
+// (d) lists the leaves.
+template <class TR, class MV, class LIST>
+S4B_HD inline bool tv_subtree_pass(const TR& cur, TR& pt, const MV& m, int nd, bool checkRules, double& subCur, double& subPt, LIST& list, int& numLeaves) {
+  double sc = 0.0, sp = 0.0; int nl = 0;
+  int depth = tv_depth_of(cur, nd), node, k; Walker<TR> w(pt, nd);
+  while (w.next(node, k)) {
+    if (k == 2) { --depth; continue; }
+    const int naC = (int)cur.na.get(node), naP = (int)pt.na.get(node);
+    if (k == 0) {
+      list.set(nl++, (int16_t)node);
+      sc += naC == 0 ? 0.0 : mv_log1m_pg(m, depth);
+      sp += naP == 0 ? 0.0 : mv_log1m_pg(m, depth);
+      continue;
+    }
+    int loC, hiC, loP, hiP;
+    tv_interval(cur, m, node, cur.var.get(node), loC, hiC);
+    tv_interval(pt, m, node, pt.var.get(node), loP, hiP);
+    const int sP = (int)pt.cut.get(node);
+    if (checkRules && (sP < loP || sP > hiP)) return false;
+    {
+      double r = naC == 0 ? -INFINITY : mv_log_pg(m, depth);
+      r += -mv_log_int(m, naC);
+      const int width = hiC - loC + 1;
+      r += (width >= 1 && width < m.logIntLen) ? -mv_log_int(m, width) : -log((double)width);
+      sc += r;
+    }
+    {
+      double r = naP == 0 ? -INFINITY : mv_log_pg(m, depth);
+      r += -mv_log_int(m, naP);
+      const int width = hiP - loP + 1;
+      r += (width >= 1 && width < m.logIntLen) ? -mv_log_int(m, width) : -log((double)width);
+      sp += r;
+    }
+    const int L = pt.left.get(node), R = pt.right.get(node);
+    const int hiL = sP - 1 < hiP ? sP - 1 : hiP, loR = sP + 1 > loP ? sP + 1 : loP;
+    const int goneL = (loP <= hiP && loP > hiL) ? 1 : 0, goneR = (loP <= hiP && loR > hiP) ? 1 : 0;
+    pt.na.set(L, (int16_t)(naP - goneL)); pt.na.set(R, (int16_t)(naP - goneR));
+    pt.dep.set(L, (int16_t)(depth + 1)); pt.dep.set(R, (int16_t)(depth + 1));
+    ++depth;
+  }
+  subCur = sc; subPt = sp; numLeaves = nl;
+  return true;
+}
+
 // ------------------------------------------------------------------ propose
 // Fills `pr` and the tables for the next update of tree `cur` (hwm = slots in use).  Preconditions: the
 // structure cache `ca` of `cur` is valid (tv_rebuild_cache), the proposed tree is a copy of `cur` (memo
@@ -476,7 +540,7 @@ S4B_HD inline int propose(const TR& cur, int hwm, const MV& m, RNG* rng, Proposa
     }
     return 0;
   }
-  int nd;
+  int nd; bool isSwap = false;
   if (u < m.pBD + m.pSwap) {
     pr->type = MOVE_SWAP;
     int g = 0;   // internal nodes with at least one internal child, post-order
@@ -500,7 +564,7 @@ S4B_HD inline int propose(const TR& cur, int hwm, const MV& m, RNG* rng, Proposa
     pt.var.set(nd, cv); pt.cut.set(nd, cs);
     if (both) { pt.var.set(L, pv); pt.cut.set(L, ps); pt.var.set(R, pv); pt.cut.set(R, ps); }
     else { pt.var.set(child, pv); pt.cut.set(child, ps); }
-    if (!tv_rules_valid(pt, m, nd)) return 0;
+    isSwap = true;
   } else {
     pr->type = MOVE_CHANGE;
     if (ni == 0) return 0;
@@ -510,8 +574,7 @@ S4B_HD inline int propose(const TR& cur, int hwm, const MV& m, RNG* rng, Proposa
     pr->var = v;
     int lo, hi; tv_interval(cur, m, nd, v, lo, hi);
     int lmn = 1 << 30, lmx = -1, rmn = 1 << 30, rmx = -1;
-    tv_min_max_split(cur, cur.left.get(nd), v, lmn, lmx);
-    tv_min_max_split(cur, cur.right.get(nd), v, rmn, rmx);
+    tv_min_max_split_sides(cur, nd, v, lmn, lmx, rmn, rmx);
     if (lmx >= 0 && lmx + 1 > lo) lo = lmx + 1;
     if (rmx >= 0 && rmn - 1 < hi) hi = rmn - 1;
     if (hi < lo) return 0;
@@ -519,11 +582,13 @@ S4B_HD inline int propose(const TR& cur, int hwm, const MV& m, RNG* rng, Proposa
     pr->split = s;
     pt.var.set(nd, (int16_t)v); pt.cut.set(nd, (uint16_t)s);
   }
-  // swap / change: only the subtree under nd changes its prior terms; its leaves keep their DFS order
-  tv_fill_info(pt, m, nd);
+  // swap / change: only the subtree under nd changes its prior terms; its leaves keep their DFS order.  One walk
+  // checks the rules (swap), fills the memo of the proposed subtree, sums the own prior terms of both trees (same
+  // shape, same order) and lists the leaves.
+  double subCur = 0.0, subPt = 0.0; int nb = 0;
+  if (!tv_subtree_pass(cur, pt, m, nd, isSwap, subCur, subPt, tb.list, nb)) return 0;
   pr->XLogPi = ca.logPi;
-  pr->YLogPi = (ca.logPi - tv_log_prior_subtree(cur, m, nd)) + tv_log_prior_subtree(pt, m, nd);
-  int nb = tv_list_leaves(pt, nd, tb.list);
+  pr->YLogPi = (ca.logPi - subCur) + subPt;
   for (int i = 0; i < nb; ++i) { int lf = tb.list.get(i); tb.binB.set(lf, (int16_t)(nl + i)); tb.insub.set(lf, 1); }
   pr->nbB = nb; pr->status = 1;
   return 0;
