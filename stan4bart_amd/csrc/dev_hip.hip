@@ -550,11 +550,17 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
   m.pg.load(a.model.pgDepth[lane]); m.lpg.load(a.model.logPg[lane]); m.l1pg.load(a.model.log1mPg[lane]);
   m.li0.load(a.model.logInt[lane < m.logIntLen ? lane : 0]); m.li1.load(a.model.logInt[64 + lane < m.logIntLen ? 64 + lane : 0]);
   m.nc0 = a.numCuts[lane < a.P ? lane : 0]; m.nc1 = a.numCuts[64 + lane < a.P ? 64 + lane : 0];
+  // tree `next`: the candidates fetch it in this hop; the decider only if it ends up proposing itself (sweep start, or no
+  // candidate matched), one extra hop then
   WaveTree curN; WaveCache caN; WaveTables tbN;
-  curN.var.r = tI[TF_VAR * ts + oN + li]; curN.cut.r = ((uint16_t*)tI)[TF_CUT * ts + oN + li]; curN.left.r = tI[TF_LEFT * ts + oN + li];
-  curN.right.r = tI[TF_RIGHT * ts + oN + li]; curN.parent.r = tI[TF_PARENT * ts + oN + li]; curN.na.r = tI[TF_NA * ts + oN + li];
-  curN.dep.r = tI[TF_DEP * ts + oN + li]; curN.nc = nc < 64 ? nc : 64;
-  caN.leaf.r = tI[TF_LEAF * ts + oN + li]; caN.pre.r = tI[TF_PRE * ts + oN + li]; caN.post.r = tI[TF_POST * ts + oN + li];
+  curN.nc = nc < 64 ? nc : 64;
+  auto loadNext = [&]() {
+    curN.var.r = laneIn ? (int)tI[TF_VAR * ts + oN + li] : (int)NODE_FREE; curN.cut.r = ((uint16_t*)tI)[TF_CUT * ts + oN + li]; curN.left.r = tI[TF_LEFT * ts + oN + li];
+    curN.right.r = tI[TF_RIGHT * ts + oN + li]; curN.parent.r = tI[TF_PARENT * ts + oN + li]; curN.na.r = tI[TF_NA * ts + oN + li];
+    curN.dep.r = tI[TF_DEP * ts + oN + li];
+    caN.leaf.r = tI[TF_LEAF * ts + oN + li]; caN.pre.r = tI[TF_PRE * ts + oN + li]; caN.post.r = tI[TF_POST * ts + oN + li];
+  };
+  if (isCand) loadNext();
   WaveTree curT; WaveTables tbT; WaveCache caT; WaveArrD mu, muOld; WaveArr<int32_t> cnt;
   if (isDecider) {
     curT.var.r = tI[TF_VAR * ts + oT + li]; curT.cut.r = ((uint16_t*)tI)[TF_CUT * ts + oT + li]; curT.left.r = tI[TF_LEFT * ts + oT + li];
@@ -571,7 +577,6 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
   // ---- first uses
   m.li0.load(lane < m.logIntLen ? m.li0.mine() : 0.0); m.li1.load(64 + lane < m.logIntLen ? m.li1.mine() : 0.0);
   m.nc0 = lane < a.P ? m.nc0 : 0; m.nc1 = 64 + lane < a.P ? m.nc1 : 0;
-  if (!laneIn) { curN.var.r = (int)NODE_FREE; }
 #pragma unroll
   for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; if (i < MTW) ((uint32_t*)&S.rng[slot])[i] = mtw[j]; }
   Proposal prT; g.proposal(prT);
@@ -681,6 +686,7 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
   }
 
   // ================================================================ proposal of tree `next` (one call site for all roles)
+  if (isDecider) loadNext();
   bool rebuilt = false;
   S4B_PTICK(tc2);
   if (!caN.valid) { tv_rebuild_cache(curN, m, caN); rebuilt = true; }

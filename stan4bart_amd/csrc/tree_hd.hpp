@@ -672,11 +672,13 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
       if (binCnt.get(br) == 0.0) oldEmpty = true; else oldLL += wk.ll.get(br);
       double c = binCnt.get(bl) + binCnt.get(br), s = binSum.get(bl) + binSum.get(br);
       if (c == 0.0) newEmpty = true; else newLL = leaf_loglik(c, s, sigma2, m.leafPrec);
-    } else {                             // swap / change: same leaves (DFS order) under nd before and after
-      int no = tv_list_leaves(cur, nd, tb.list);
-      for (int i = 0; i < no; ++i) {
-        int lf = tb.list.get(i);
-        int ba = tb.binA.get(lf), bb = tb.binB.get(lf);
+    } else {                             // swap / change: same leaves (DFS order) under nd before and after —
+      const int nlAll = ca.nl;           // exactly the leaves of the tree that carry a B bin, in the cached DFS order
+      for (int i = 0; i < nlAll; ++i) {
+        int lf = ca.leaf.get(i);
+        int bb = tb.binB.get(lf);
+        if (bb < 0) continue;
+        int ba = tb.binA.get(lf);
         if (binCnt.get(ba) == 0.0) oldEmpty = true; else oldLL += wk.ll.get(ba);
         if (binCnt.get(bb) == 0.0) newEmpty = true; else newLL += wk.ll.get(bb);
       }
