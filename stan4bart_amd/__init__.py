@@ -6,4 +6,5 @@ this package is the host-side mirror of the reference's R fit driver for that pa
 from .abi import Sampler, SamplerArgs  # noqa: F401
 from .fit import GroupTerm, make_sampler_args, stan4bart_fit, fit_worker  # noqa: F401
 from .friedman import generate_friedman_data  # noqa: F401
+from .generics import Stan4bartFit, stan4bart  # noqa: F401
 from .rcompat import RRng  # noqa: F401

@@ -1,0 +1,110 @@
+"""The user surface around the hot path (stan4bart_amd/generics.py: stan4bart(), extract, fitted, predict), following the
+reference's own tests: predict == extract for duplicated rows (tests/testthat/test-01-continuous.R:204-246,
+test-02-binary.R:81-123), component identities, shapes and argument errors (test-01:21-149)."""
+import numpy as np
+import pytest
+
+from stan4bart_amd import GroupTerm, generate_friedman_data
+from stan4bart_amd.abi import Sampler
+from stan4bart_amd.generics import combine_chains_f, stan4bart
+
+
+def _data(n=120, binary=False, seed_rows=17):
+    d = generate_friedman_data(n, ranef=True, causal=True, binary=binary, p=10)
+    x = d["x"]
+    xb = x[:, [j for j in range(10) if j != 3]]
+    X = np.column_stack([x[:, 3], d["z"]])
+    groups = [GroupTerm(d["g1"], x[:, 3], "g.1"), GroupTerm(d["g2"], None, "g.2")]
+    rows = np.arange(seed_rows)
+    groups_t = [GroupTerm(np.asarray(d["g1"])[rows], x[rows, 3], "g.1"), GroupTerm(np.asarray(d["g2"])[rows], None, "g.2")]
+    return d, xb, X, groups, rows, groups_t
+
+
+def _fit(lib, prefix, binary=False, chains=2, keep_trees=True):
+    d, xb, X, groups, rows, groups_t = _data(binary=binary)
+    fit = stan4bart(d["y"], xb, X=X, groups=groups, x_bart_test=xb[rows], X_test=X[rows], groups_test=groups_t,
+                    family="binomial" if binary else "gaussian", chains=chains, seed=99, iter=14, warmup=6,
+                    bart_args={"n.trees": 9, "keepTrees": keep_trees},
+                    make_sampler=lambda a, st: Sampler(lib, prefix, a, st))
+    return fit, (d, xb, X, groups, rows, groups_t)
+
+
+def _check_surface(fit, data):
+    d, xb, X, groups, rows, groups_t = data
+    n, S, C = len(d["y"]), 8, 2
+    ev = fit.extract("ev", combine_chains=False)
+    assert ev.shape == (n, S, C)
+    assert fit.extract("ev").shape == (n, S * C)
+    np.testing.assert_array_equal(fit.extract("ev")[:, :S], ev[:, :, 0])          # chain 1's draws first
+    assert fit.extract("ev", include_warmup=True, combine_chains=False).shape == (n, 6 + S, C)
+    assert fit.extract("ev", include_warmup="only", combine_chains=False).shape == (n, 6, C)
+    # components add up; fitted = posterior mean
+    parts = sum(fit.extract(t, combine_chains=False) for t in ("indiv.bart", "indiv.fixef", "indiv.ranef"))
+    if fit.family == "binomial":
+        from stan4bart_amd.generics import _pnorm
+        parts = _pnorm(parts)
+    np.testing.assert_allclose(ev, parts, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(fit.fitted("ev"), fit.extract("ev").mean(axis=1), rtol=1e-12)
+    # test sample == the same rows of the training sample (duplicated rows)
+    for t in ("ev", "indiv.bart", "indiv.fixef", "indiv.ranef"):
+        np.testing.assert_allclose(fit.extract(t, sample="test", combine_chains=False), fit.extract(t, combine_chains=False)[rows],
+                                   rtol=1e-9, atol=1e-9)
+    # predict from the kept trees == extract (reference test-01:204-246)
+    for t in ("ev", "indiv.bart", "indiv.fixef", "indiv.ranef"):
+        p = fit.predict(x_bart=xb[rows], X=X[rows], groups=groups_t, type=t, combine_chains=False)
+        np.testing.assert_allclose(p, fit.extract(t, combine_chains=False)[rows], rtol=1e-9, atol=1e-9)
+    # parametric pieces
+    assert fit.extract("fixef").shape == (2, S * C)
+    re = fit.extract("ranef", combine_chains=False)
+    assert re["g.1"].shape == (2, 5, S, C) and re["g.2"].shape == (1, 8, S, C)
+    Sg = fit.extract("Sigma", combine_chains=False)
+    assert Sg["g.1"].shape == (2, 2, S, C) and np.all(np.linalg.eigvalsh(Sg["g.1"][:, :, 0, 0]) >= -1e-12)
+    assert fit.extract("varcount").shape == (9, S * C) and np.all(fit.extract("varcount").sum(axis=0) >= 0)
+    if fit.family == "gaussian":
+        assert fit.extract("sigma").shape == (S * C,) and np.all(fit.extract("sigma") > 0)
+        ppd = fit.extract("ppd", seed=1)
+        assert ppd.shape == (n, S * C) and np.std(ppd - fit.extract("ev")) > 0
+    else:
+        with pytest.raises(ValueError, match="sigma"):
+            fit.extract("sigma")
+        assert set(np.unique(fit.extract("ppd", seed=1))) <= {0.0, 1.0}
+        assert np.all((ev >= 0) & (ev <= 1))
+    # unseen grouping levels: zero effect, or a draw from Sigma
+    g_new = [GroupTerm(np.full(3, 6), X[:3, 0], "g.1"), GroupTerm(np.asarray(d["g2"])[:3], None, "g.2")]
+    r0 = fit.predict(x_bart=xb[:3], X=X[:3], groups=g_new, type="indiv.ranef", sample_new_levels=False, combine_chains=False)
+    g2_only = fit.extract("ranef", combine_chains=False)["g.2"][0][np.asarray(d["g2"])[:3] - 1]
+    np.testing.assert_allclose(r0, g2_only, rtol=1e-12)
+    r1 = fit.predict(x_bart=xb[:3], X=X[:3], groups=g_new, type="indiv.ranef", sample_new_levels=True, seed=3, combine_chains=False)
+    assert np.std(r1 - r0) > 0
+    trees = fit.extract("trees")
+    assert len(trees) == C and set(trees[0]) == {"tree", "n", "var", "split", "value"}
+    with pytest.raises(ValueError):
+        fit.extract("nonsense")
+    fit.close()
+
+
+def test_combine_chains():
+    x = np.arange(24).reshape(2, 3, 4)
+    c = combine_chains_f(x)
+    assert c.shape == (2, 12) and list(c[0, :3]) == [0, 4, 8] and list(c[0, 3:6]) == [1, 5, 9]
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_generics_host_logic(emul_lib, binary):
+    fit, data = _fit(emul_lib, "emu_", binary=binary)
+    _check_surface(fit, data)
+
+
+def test_predict_needs_kept_trees(emul_lib):
+    fit, data = _fit(emul_lib, "emu_", keep_trees=False, chains=1)
+    with pytest.raises(ValueError, match="keepTrees"):
+        fit.predict(x_bart=data[1][:3], X=data[2][:3], groups=data[5], type="ev")
+    with pytest.raises(ValueError, match="keepTrees"):
+        fit.extract("trees")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binary", [False, True])
+def test_generics_on_hip(hip_lib, binary):
+    fit, data = _fit(hip_lib, "s4b_", binary=binary)
+    _check_surface(fit, data)
