@@ -65,7 +65,7 @@ typedef struct {
 typedef struct {
   int64_t N; int32_t K;
   int32_t is_binary, has_intercept, has_weights;
-  int32_t prior_dist, prior_dist_for_aux;           /* 0 none,1 normal,2 student_t / aux: +3 exponential */
+  int32_t prior_dist, prior_dist_for_aux;           /* 0 none,1 normal,2 student_t,3 hs,4 hs_plus,5 laplace,6 lasso,7 product_normal / aux: 0..2, 3 exponential */
   const double* X;            /* N x K, column-centred fixed-effect design (R/rstanarm_functions.R:420-446) */
   const double* y;            /* N */
   const double* weights;      /* N or NULL */
@@ -86,6 +86,10 @@ typedef struct {
   const double* w;            /* num_non_zero: CSR values of Z  */
   const int32_t* v;           /* num_non_zero: 0-based columns  */
   const int32_t* u;           /* N + 1: 0-based row starts      */
+  /* coefficient prior families beyond normal / student_t (continuous.stan:124-144, 298-322, 382-414):
+   * prior_dist 3 hs, 4 hs_plus, 5 laplace, 6 lasso, 7 product_normal */
+  double global_prior_df, global_prior_scale, slab_df, slab_scale;   /* hs, hs_plus */
+  const int32_t* num_normals; /* K (>= 2 each), product_normal only, else NULL */
 } s4b_stan_data;
 
 /* the `stanControl` list with the reference defaults (src/stan_sampler.cpp:395-458) */

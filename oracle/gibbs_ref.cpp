@@ -57,6 +57,8 @@ static StanData convert(const s4b_stan_data& d) {
   if (d.K) { s.prior_scale.assign(d.prior_scale, d.prior_scale + d.K); s.prior_mean.assign(d.prior_mean, d.prior_mean + d.K);
              s.prior_df.assign(d.prior_df, d.prior_df + d.K); }
   s.prior_scale_for_aux = d.prior_scale_for_aux; s.prior_mean_for_aux = d.prior_mean_for_aux; s.prior_df_for_aux = d.prior_df_for_aux;
+  s.global_prior_df = d.global_prior_df; s.global_prior_scale = d.global_prior_scale; s.slab_df = d.slab_df; s.slab_scale = d.slab_scale;
+  if (d.prior_dist == 7) { if (!d.num_normals) throw std::invalid_argument("product_normal needs num_normals"); s.num_normals.assign(d.num_normals, d.num_normals + d.K); }
   s.t = d.t; s.q = d.q; s.len_theta_L = d.len_theta_L;
   if (d.t) { s.p.assign(d.p, d.p + d.t); s.l.assign(d.l, d.l + d.t); s.shape.assign(d.shape, d.shape + d.t); s.scale.assign(d.scale, d.scale + d.t); }
   if (d.len_concentration) s.concentration.assign(d.concentration, d.concentration + d.len_concentration);
@@ -241,7 +243,12 @@ int orc_get_stan_par_names(s4b_sampler* s, char* buf, size_t cap) {
   const StanModel& m = *s->model;
   std::string o = "lp__\naccept_stat__\nstepsize__\ntreedepth__\nn_leapfrog__\ndivergent__\nenergy__";
   auto add = [&](const char* base, int cnt) { for (int i = 1; i <= cnt; ++i) o += "\n" + std::string(base) + "." + std::to_string(i); };
-  add("z_beta", m.dat.K); add("z_b", m.dat.q); add("z_T", m.len_z_T); add("rho", m.len_rho); add("zeta", m.len_conc); add("tau", m.dat.t);
+  add("z_beta", m.n_z_beta); add("global", m.hs);
+  for (int k = 1; k <= (m.hs ? m.dat.K : 0); ++k) for (int j = 1; j <= m.hs; ++j) o += "\nlocal." + std::to_string(j) + "." + std::to_string(k);
+  add("caux", m.hs > 0 ? 1 : 0);
+  for (int k = 1; k <= m.n_mix; ++k) o += "\nmix.1." + std::to_string(k);
+  add("one_over_lambda", m.n_lambda);
+  add("z_b", m.dat.q); add("z_T", m.len_z_T); add("rho", m.len_rho); add("zeta", m.len_conc); add("tau", m.dat.t);
   if (!m.dat.is_binary) { add("aux_unscaled", 1); add("aux", 1); }
   add("beta", m.dat.K); add("b", m.dat.q); add("theta_L", m.dat.len_theta_L);
   if (o.size() + 1 > cap) { g_err = "name buffer too small"; return 1; }

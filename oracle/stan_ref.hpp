@@ -14,7 +14,8 @@
 // Reverse-mode AD is replaced by: forward-mode dual numbers over the O(D) parameter transforms
 // (so the Stan program is followed line by line) + the closed-form adjoint of the Gaussian
 // likelihood for the O(N) part.  Supported prior families: prior_dist in {0 none, 1 normal,
-// 2 student_t (Cornish-Fisher)}, prior_dist_for_aux in {0,1,2,3}, decov covariance prior.
+// 2 student_t (Cornish-Fisher), 3 hs, 4 hs_plus, 5 laplace, 6 lasso, 7 product_normal}, prior_dist_for_aux in
+// {0,1,2,3}, decov covariance prior.
 #ifndef ORACLE_STAN_REF_HPP
 #define ORACLE_STAN_REF_HPP
 
@@ -68,6 +69,8 @@ struct StanData {
   std::vector<double> shape, scale, concentration, regularization;
   std::vector<double> w; std::vector<int> v; std::vector<int> u;   // CSR of Z
   int has_weights = 0; std::vector<double> weights;
+  double global_prior_df = 1, global_prior_scale = 1, slab_df = 1, slab_scale = 1;
+  std::vector<int> num_normals;
   std::vector<double> offset_;
 };
 
@@ -75,6 +78,7 @@ class StanModel {
  public:
   StanData dat;
   int len_z_T = 0, len_rho = 0, len_conc = 0;
+  int hs = 0, n_z_beta = 0, n_mix = 0, n_lambda = 0;   // extra blocks of the hs / laplace / lasso / product_normal priors
   std::vector<double> delta;
   int D = 0;
   int n_constrained = 0, n_row = 0;   // write_array length; +7 sampler columns
@@ -82,7 +86,13 @@ class StanModel {
 
   explicit StanModel(const StanData& d) : dat(d) {
     if (dat.has_intercept) throw std::invalid_argument("has_intercept = 1 is not supported (BART supplies the intercept)");
-    if (dat.prior_dist < 0 || dat.prior_dist > 2) throw std::invalid_argument("prior_dist must be 0, 1 or 2");
+    if (dat.prior_dist < 0 || dat.prior_dist > 7) throw std::invalid_argument("prior_dist must be in 0..7");
+    hs = dat.prior_dist == 3 ? 2 : (dat.prior_dist == 4 ? 4 : 0);
+    if (hs && dat.is_binary) throw std::invalid_argument("hs priors scale with the residual sd: not available for binary responses");
+    n_z_beta = dat.K;
+    if (dat.prior_dist == 7) { n_z_beta = 0; for (int k = 0; k < dat.K; ++k) n_z_beta += dat.num_normals[(size_t)k]; }
+    n_mix = (dat.prior_dist == 5 || dat.prior_dist == 6) ? dat.K : 0;
+    n_lambda = dat.prior_dist == 6 ? 1 : 0;
     int sum_p = 0;
     for (int i = 0; i < dat.t; ++i) {
       sum_p += dat.p[i];
@@ -91,7 +101,7 @@ class StanModel {
     }
     len_rho = sum_p - dat.t;
     len_conc = (int)delta.size();
-    D = dat.K + dat.q + len_z_T + len_rho + len_conc + dat.t + (dat.is_binary ? 0 : 1);
+    D = n_z_beta + hs + hs * dat.K + (hs > 0 ? 1 : 0) + n_mix + n_lambda + dat.q + len_z_T + len_rho + len_conc + dat.t + (dat.is_binary ? 0 : 1);
     n_constrained = D + (dat.is_binary ? 0 : 1) + dat.K + dat.q + dat.len_theta_L;
     n_row = 7 + n_constrained;
     if ((int64_t)dat.offset_.size() != dat.N) dat.offset_.assign(dat.N, 0.0);
@@ -113,7 +123,15 @@ class StanModel {
     auto var = [&](int idx) { Dual x(qv[(size_t)idx], Dn); x.d[(size_t)idx] = 1.0; return x; };
     int pos = 0;
     std::vector<Dual> z_beta, z_b, z_T, rho, zeta, tau;
-    for (int k = 0; k < dat.K; ++k) z_beta.push_back(var(pos++));
+    for (int k = 0; k < n_z_beta; ++k) z_beta.push_back(var(pos++));
+    // lower-bounded blocks of the shrinkage priors (continuous.stan:266-270; arrays of vectors are read array-major)
+    auto lb0e = [&](int idx) { Dual x = var(idx); if (jacobian) lp = lp + x; return exp(x); };
+    std::vector<Dual> global, caux, one_over_lambda; std::vector<std::vector<Dual>> local((size_t)hs), mix(n_mix ? 1 : 0);
+    for (int j = 0; j < hs; ++j) global.push_back(lb0e(pos++));
+    for (int j = 0; j < hs; ++j) for (int k = 0; k < dat.K; ++k) local[(size_t)j].push_back(lb0e(pos++));
+    if (hs > 0) caux.push_back(lb0e(pos++));
+    for (int k = 0; k < n_mix; ++k) mix[0].push_back(lb0e(pos++));
+    if (n_lambda) one_over_lambda.push_back(lb0e(pos++));
     for (int j = 0; j < dat.q; ++j) z_b.push_back(var(pos++));
     for (int j = 0; j < len_z_T; ++j) z_T.push_back(var(pos++));
     for (int j = 0; j < len_rho; ++j) {   // lub_constrain(x, 0, 1, lp)
@@ -143,16 +161,43 @@ class StanModel {
     }
     T.sigma = aux;
     T.beta.clear();
-    for (int k = 0; k < dat.K; ++k) {
+    if (dat.prior_dist <= 2) for (int k = 0; k < dat.K; ++k) {
       if (dat.prior_dist == 0) T.beta.push_back(z_beta[k]);
       else if (dat.prior_dist == 1) T.beta.push_back(z_beta[k] * dat.prior_scale[k] + dat.prior_mean[k]);
       else T.beta.push_back(CFt(z_beta[k], dat.prior_df[k]) * dat.prior_scale[k] + dat.prior_mean[k]);
+    } else if (hs > 0) {   // hs_prior / hsplus_prior (continuous.stan:124-144), error_scale = aux
+      Dual c2 = caux[0] * (dat.slab_scale * dat.slab_scale);
+      Dual tauG = global[0] * sqrt(global[1]) * dat.global_prior_scale * aux;
+      for (int k = 0; k < dat.K; ++k) {
+        Dual lam = local[0][(size_t)k] * sqrt(local[1][(size_t)k]);
+        if (hs == 4) lam = lam * (local[2][(size_t)k] * sqrt(local[3][(size_t)k]));
+        Dual lam2 = square(lam);
+        Dual tilde = sqrt(c2 * lam2 / (c2 + square(tauG) * lam2));
+        T.beta.push_back(z_beta[(size_t)k] * tilde * tauG);
+      }
+    } else if (dat.prior_dist == 5) {
+      for (int k = 0; k < dat.K; ++k) T.beta.push_back(sqrt(mix[0][(size_t)k] * 2.0) * dat.prior_scale[(size_t)k] * z_beta[(size_t)k] + dat.prior_mean[(size_t)k]);
+    } else if (dat.prior_dist == 6) {
+      for (int k = 0; k < dat.K; ++k)
+        T.beta.push_back(one_over_lambda[0] * dat.prior_scale[(size_t)k] * sqrt(mix[0][(size_t)k] * 2.0) * z_beta[(size_t)k] + dat.prior_mean[(size_t)k]);
+    } else {               // product_normal
+      int zp = 0;
+      for (int k = 0; k < dat.K; ++k) {
+        Dual bk = z_beta[(size_t)zp++];
+        for (int n2 = 2; n2 <= dat.num_normals[(size_t)k]; ++n2) bk = bk * z_beta[(size_t)zp++];
+        T.beta.push_back(bk * std::pow(dat.prior_scale[(size_t)k], (double)dat.num_normals[(size_t)k]) + dat.prior_mean[(size_t)k]);
+      }
     }
     make_theta_L(aux, tau, zeta, rho, z_T, T.theta_L);
     make_b(z_b, T.theta_L, T.b);
 
     T.constrained.clear();
     for (auto& x : z_beta) T.constrained.push_back(x);
+    for (auto& x : global) T.constrained.push_back(x);
+    for (int k = 0; k < dat.K; ++k) for (int j = 0; j < hs; ++j) T.constrained.push_back(local[(size_t)j][(size_t)k]);   // written vector-index-major
+    for (auto& x : caux) T.constrained.push_back(x);
+    for (int k = 0; k < n_mix; ++k) T.constrained.push_back(mix[0][(size_t)k]);
+    for (auto& x : one_over_lambda) T.constrained.push_back(x);
     for (auto& x : z_b) T.constrained.push_back(x);
     for (auto& x : z_T) T.constrained.push_back(x);
     for (auto& x : rho) T.constrained.push_back(x);
@@ -171,8 +216,29 @@ class StanModel {
         lp = lp + (t + (std::lgamma((nu + 1.0) / 2.0) - std::lgamma(nu / 2.0) - 0.5 * std::log(nu * M_PI))) - log_half;
       } else lp = lp - aux_unscaled;
     }
-    if (dat.prior_dist == 1 || dat.prior_dist == 2)
+    if (dat.prior_dist >= 1)
       for (auto& z : z_beta) lp = lp + (square(z) * -0.5 + NEG_LOG_SQRT_TWO_PI);
+    {
+      const double log_half = -0.693147180559945286;
+      auto half_normal = [&](const std::vector<Dual>& v) { for (auto& x : v) lp = lp + (square(x) * -0.5 + NEG_LOG_SQRT_TWO_PI); lp = lp - log_half; };
+      auto inv_gamma = [&](const Dual& x, double al, double be) { lp = lp + (log(x) * (-(al + 1.0)) - cst(be, Dn) / x + (al * std::log(be) - std::lgamma(al))); };
+      if (hs > 0) {
+        half_normal(local[0]);
+        for (int k = 0; k < dat.K; ++k) inv_gamma(local[1][(size_t)k], 0.5 * dat.prior_df[(size_t)k], 0.5 * dat.prior_df[(size_t)k]);
+        if (hs == 4) {
+          half_normal(local[2]);
+          for (int k = 0; k < dat.K; ++k) inv_gamma(local[3][(size_t)k], 0.5 * dat.prior_scale[(size_t)k], 0.5 * dat.prior_scale[(size_t)k]);
+        }
+        lp = lp + (square(global[0]) * -0.5 + NEG_LOG_SQRT_TWO_PI) - log_half;
+        inv_gamma(global[1], 0.5 * dat.global_prior_df, 0.5 * dat.global_prior_df);
+        inv_gamma(caux[0], 0.5 * dat.slab_df, 0.5 * dat.slab_df);
+      }
+      for (int k = 0; k < n_mix; ++k) lp = lp - mix[0][(size_t)k];   // exponential_lpdf(mix | 1)
+      if (n_lambda) {   // chi_square_lpdf(one_over_lambda | prior_df[1])
+        double nu = dat.prior_df[0];
+        lp = lp + (log(one_over_lambda[0]) * (0.5 * nu - 1.0) - one_over_lambda[0] * 0.5 - (0.5 * nu * std::log(2.0) + std::lgamma(0.5 * nu)));
+      }
+    }
     // decov_lp
     for (auto& z : z_b) lp = lp + (square(z) * -0.5 + NEG_LOG_SQRT_TWO_PI);
     for (auto& z : z_T) lp = lp + (square(z) * -0.5 + NEG_LOG_SQRT_TWO_PI);

@@ -47,7 +47,9 @@ class StanData(C.Structure):
                 ("shape", c_double_p), ("scale", c_double_p),
                 ("concentration", c_double_p), ("regularization", c_double_p),
                 ("num_non_zero", C.c_int64),
-                ("w", c_double_p), ("v", c_int32_p), ("u", c_int32_p)]
+                ("w", c_double_p), ("v", c_int32_p), ("u", c_int32_p),
+                ("global_prior_df", C.c_double), ("global_prior_scale", C.c_double),
+                ("slab_df", C.c_double), ("slab_scale", C.c_double), ("num_normals", c_int32_p)]
 
 
 class StanControl(C.Structure):
@@ -122,6 +124,11 @@ class SamplerArgs:
     prior_scale_for_aux: float = 1.0
     prior_mean_for_aux: float = 0.0
     prior_df_for_aux: float = 1.0
+    global_prior_df: float = 1.0            # hs / hs_plus
+    global_prior_scale: float = 0.01
+    slab_df: float = 4.0
+    slab_scale: float = 2.5
+    num_normals: Optional[Sequence[int]] = None   # product_normal
     p: Sequence[int] = ()
     l: Sequence[int] = ()
     shape: Sequence[float] = ()
@@ -212,7 +219,10 @@ class Sampler:
                       len_concentration=len(conc), len_regularization=len(reg), reserved=0,
                       p=_ip(p_arr), l=_ip(l_arr), shape=_dp(shape), scale=_dp(scale),
                       concentration=_dp(conc), regularization=_dp(reg), num_non_zero=len(w),
-                      w=_dp(w), v=_ip(v), u=_ip(u))
+                      w=_dp(w), v=_ip(v), u=_ip(u),
+                      global_prior_df=a.global_prior_df, global_prior_scale=a.global_prior_scale, slab_df=a.slab_df,
+                      slab_scale=a.slab_scale,
+                      num_normals=_ip(keep(_i32(a.num_normals))) if a.num_normals is not None else None)
         sc = StanControl(seed=a.seed & 0xFFFFFFFF, skip=a.skip, init_r=a.init_r, adapt_gamma=a.adapt_gamma,
                          adapt_delta=a.adapt_delta, adapt_kappa=a.adapt_kappa, adapt_t0=a.adapt_t0,
                          adapt_init_buffer=a.adapt_init_buffer, adapt_term_buffer=a.adapt_term_buffer,

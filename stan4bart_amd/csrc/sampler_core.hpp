@@ -61,7 +61,9 @@ class SamplerCore {
     binary_ = cc->is_binary != 0;
     if (sd->has_weights) throw std::invalid_argument("weights are not supported by the device path yet");
     if (sd->has_intercept) throw std::invalid_argument("has_intercept = 1 is not supported (BART supplies the intercept)");
-    if (sd->prior_dist < 0 || sd->prior_dist > 2) throw std::invalid_argument("prior_dist must be 0, 1 or 2");
+    if (sd->prior_dist < 0 || sd->prior_dist > 7) throw std::invalid_argument("prior_dist must be in 0..7");
+    if ((sd->prior_dist == 3 || sd->prior_dist == 4) && cc->is_binary) throw std::invalid_argument("hs priors scale with the residual sd: not available for binary responses");
+    if (sd->prior_dist == 7 && !sd->num_normals) throw std::invalid_argument("product_normal needs num_normals");
     n_ = (size_t)bd->n; P_ = bd->p; T_ = bc->n_trees; nTest_ = (size_t)bd->n_test;
     warmup_ = cc->warmup; verbose_ = cc->verbose; keepFits_ = cc->keep_fits != 0; offsetType_ = cc->offset_type;
     callback_ = cc->callback; callbackUser_ = cc->callback_user;
@@ -80,6 +82,8 @@ class SamplerCore {
     if (sd->K) { sp.prior_scale.assign(sd->prior_scale, sd->prior_scale + sd->K); sp.prior_mean.assign(sd->prior_mean, sd->prior_mean + sd->K);
                  sp.prior_df.assign(sd->prior_df, sd->prior_df + sd->K); }
     sp.prior_scale_for_aux = sd->prior_scale_for_aux; sp.prior_mean_for_aux = sd->prior_mean_for_aux; sp.prior_df_for_aux = sd->prior_df_for_aux;
+    sp.global_prior_df = sd->global_prior_df; sp.global_prior_scale = sd->global_prior_scale; sp.slab_df = sd->slab_df; sp.slab_scale = sd->slab_scale;
+    if (sd->prior_dist == 7) sp.num_normals.assign(sd->num_normals, sd->num_normals + sd->K);
     if (sd->t) { sp.p.assign(sd->p, sd->p + sd->t); sp.l.assign(sd->l, sd->l + sd->t); sp.shape.assign(sd->shape, sd->shape + sd->t);
                  sp.scale.assign(sd->scale, sd->scale + sd->t); }
     if (sd->len_concentration) sp.concentration.assign(sd->concentration, sd->concentration + sd->len_concentration);
@@ -108,7 +112,7 @@ class SamplerCore {
     di.model.P = P_; di.model.Pvalid = 0;
     for (int j = 0; j < P_; ++j) if (numCuts_[(size_t)j] > 0) ++di.model.Pvalid;
     if (di.model.Pvalid == 0) throw std::invalid_argument("no predictor has a cut point");
-    di.model.numCuts = nullptr;
+    di.model.numCuts = nullptr; di.model.scratch = nullptr;
     di.model.base = bc->base; di.model.power = bc->power;
     di.model.pBD = bc->birth_or_death_prob; di.model.pSwap = bc->swap_prob; di.model.pChange = bc->change_prob; di.model.pBirth = bc->birth_prob;
     { double sd_mu = bc->node_scale / (bc->k * std::sqrt((double)T_)); di.model.leafPrec = 1.0 / (sd_mu * sd_mu); }
@@ -238,7 +242,12 @@ class SamplerCore {
     const StanSpec& m = model_->sp;
     std::string o = "lp__\naccept_stat__\nstepsize__\ntreedepth__\nn_leapfrog__\ndivergent__\nenergy__";
     auto add = [&](const char* base, int cnt) { for (int i = 1; i <= cnt; ++i) o += "\n" + std::string(base) + "." + std::to_string(i); };
-    add("z_beta", m.K); add("z_b", m.q); add("z_T", m.len_z_T); add("rho", m.len_rho); add("zeta", m.len_conc); add("tau", m.t);
+    add("z_beta", m.n_z_beta); add("global", m.hs);
+    for (int k = 1; k <= (m.hs ? m.K : 0); ++k) for (int j = 1; j <= m.hs; ++j) o += "\nlocal." + std::to_string(j) + "." + std::to_string(k);
+    add("caux", m.hs > 0 ? 1 : 0);
+    for (int k = 1; k <= m.n_mix; ++k) o += "\nmix.1." + std::to_string(k);
+    add("one_over_lambda", m.n_lambda);
+    add("z_b", m.q); add("z_T", m.len_z_T); add("rho", m.len_rho); add("zeta", m.len_conc); add("tau", m.t);
     if (!m.is_binary) { add("aux_unscaled", 1); add("aux", 1); }
     add("beta", m.K); add("b", m.q); add("theta_L", m.len_theta_L);
     return o;

@@ -60,6 +60,7 @@ inline TV operator*(TV a, double c) { return {a.t, a.t->un(a.i, a.v() * c, c)}; 
 inline TV operator*(double c, TV a) { return a * c; }
 inline TV operator/(TV a, double c) { return {a.t, a.t->un(a.i, a.v() / c, 1.0 / c)}; }
 inline TV operator-(double c, TV a) { return {a.t, a.t->un(a.i, c - a.v(), -1)}; }
+inline TV operator/(double c, TV a) { double r = c / a.v(); return {a.t, a.t->un(a.i, r, -r / a.v())}; }
 inline TV tsqrt(TV a) { double s = std::sqrt(a.v()); return {a.t, a.t->un(a.i, s, 0.5 / s)}; }
 inline TV texp(TV a) { double e = std::exp(a.v()); return {a.t, a.t->un(a.i, e, e)}; }
 inline TV tlog(TV a) { return {a.t, a.t->un(a.i, std::log(a.v()), 1.0 / a.v())}; }
@@ -74,10 +75,13 @@ struct StanSpec {
   int is_binary = 0, prior_dist = 1, prior_dist_for_aux = 3;
   std::vector<double> prior_scale, prior_mean, prior_df;
   double prior_scale_for_aux = 1, prior_mean_for_aux = 0, prior_df_for_aux = 1;
+  double global_prior_df = 1, global_prior_scale = 1, slab_df = 1, slab_scale = 1;   // hs, hs_plus
+  std::vector<int> num_normals;                                                       // product_normal
   std::vector<int> p, l;
   std::vector<double> shape, scale, concentration, regularization;
   // derived (continuous.stan transformed data, src/stan_sampler.cpp:167-182)
   int len_z_T = 0, len_rho = 0, len_conc = 0, D = 0, n_constrained = 0;
+  int hs = 0, n_z_beta = 0, n_mix = 0, n_lambda = 0;   // extra blocks of the hs / laplace / lasso / product_normal priors
   std::vector<double> delta;
   void finish() {
     int sum_p = 0; len_z_T = 0; delta.clear();
@@ -87,7 +91,11 @@ struct StanSpec {
       for (int j = 3; j <= p[i]; ++j) len_z_T += p[i] - 1;
     }
     len_rho = sum_p - t; len_conc = (int)delta.size();
-    D = K + q + len_z_T + len_rho + len_conc + t + (is_binary ? 0 : 1);
+    hs = prior_dist == 3 ? 2 : (prior_dist == 4 ? 4 : 0);
+    n_z_beta = K;
+    if (prior_dist == 7) { n_z_beta = 0; for (int k = 0; k < K; ++k) n_z_beta += num_normals[(size_t)k]; }
+    n_mix = (prior_dist == 5 || prior_dist == 6) ? K : 0; n_lambda = prior_dist == 6 ? 1 : 0;
+    D = n_z_beta + hs + hs * K + (hs > 0 ? 1 : 0) + n_mix + n_lambda + q + len_z_T + len_rho + len_conc + t + (is_binary ? 0 : 1);
     n_constrained = D + (is_binary ? 0 : 1) + K + q + len_theta_L;
   }
   int aux_pos() const { return D; }
@@ -119,7 +127,15 @@ class HostModel {
     std::vector<TV>& z_beta = w_[0]; std::vector<TV>& z_b = w_[1]; std::vector<TV>& z_T = w_[2];
     std::vector<TV>& rho = w_[3]; std::vector<TV>& zeta = w_[4]; std::vector<TV>& tau = w_[5];
     for (auto& v : w_) v.clear();
-    for (int k = 0; k < sp.K; ++k) z_beta.push_back(Q(pos++));
+    for (int k = 0; k < sp.n_z_beta; ++k) z_beta.push_back(Q(pos++));
+    // lower-bounded blocks of the shrinkage priors (continuous.stan:266-270; arrays of vectors are read array-major)
+    auto lb0e = [&](int idx) { TV x = Q(idx); if (jacobian) lp = lp + x; return texp(x); };
+    std::vector<TV> global, caux, lambda1, mix; std::vector<std::vector<TV>> local((size_t)sp.hs);
+    for (int j = 0; j < sp.hs; ++j) global.push_back(lb0e(pos++));
+    for (int j = 0; j < sp.hs; ++j) for (int k = 0; k < sp.K; ++k) local[(size_t)j].push_back(lb0e(pos++));
+    if (sp.hs > 0) caux.push_back(lb0e(pos++));
+    for (int k = 0; k < sp.n_mix; ++k) mix.push_back(lb0e(pos++));
+    if (sp.n_lambda) lambda1.push_back(lb0e(pos++));
     for (int j = 0; j < sp.q; ++j) z_b.push_back(Q(pos++));
     for (int j = 0; j < sp.len_z_T; ++j) z_T.push_back(Q(pos++));
     for (int j = 0; j < sp.len_rho; ++j) {   // lub_constrain(x, 0, 1): inv_logit, log-Jacobian -|x| - 2 log1p(exp(-|x|))
@@ -144,16 +160,43 @@ class HostModel {
     }
     F.sigma = aux;
     F.beta.clear();
-    for (int k = 0; k < sp.K; ++k) {
+    if (sp.prior_dist <= 2) for (int k = 0; k < sp.K; ++k) {
       if (sp.prior_dist == 0) F.beta.push_back(z_beta[(size_t)k]);
       else if (sp.prior_dist == 1) F.beta.push_back(z_beta[(size_t)k] * sp.prior_scale[(size_t)k] + sp.prior_mean[(size_t)k]);
       else F.beta.push_back(cornish_fisher(z_beta[(size_t)k], sp.prior_df[(size_t)k]) * sp.prior_scale[(size_t)k] + sp.prior_mean[(size_t)k]);
+    } else if (sp.hs > 0) {   // hs_prior / hsplus_prior (continuous.stan:124-144), error_scale = aux
+      TV c2 = caux[0] * (sp.slab_scale * sp.slab_scale);
+      TV tauG = global[0] * tsqrt(global[1]) * sp.global_prior_scale * aux;
+      for (int k = 0; k < sp.K; ++k) {
+        TV lam = local[0][(size_t)k] * tsqrt(local[1][(size_t)k]);
+        if (sp.hs == 4) lam = lam * (local[2][(size_t)k] * tsqrt(local[3][(size_t)k]));
+        TV lam2 = tsquare(lam);
+        TV tilde = tsqrt(c2 * lam2 / (c2 + tsquare(tauG) * lam2));
+        F.beta.push_back(z_beta[(size_t)k] * tilde * tauG);
+      }
+    } else if (sp.prior_dist == 5) {
+      for (int k = 0; k < sp.K; ++k) F.beta.push_back(tsqrt(mix[(size_t)k] * 2.0) * sp.prior_scale[(size_t)k] * z_beta[(size_t)k] + sp.prior_mean[(size_t)k]);
+    } else if (sp.prior_dist == 6) {
+      for (int k = 0; k < sp.K; ++k)
+        F.beta.push_back(lambda1[0] * sp.prior_scale[(size_t)k] * tsqrt(mix[(size_t)k] * 2.0) * z_beta[(size_t)k] + sp.prior_mean[(size_t)k]);
+    } else {               // product_normal
+      int zp = 0;
+      for (int k = 0; k < sp.K; ++k) {
+        TV bk = z_beta[(size_t)zp++];
+        for (int n2 = 2; n2 <= sp.num_normals[(size_t)k]; ++n2) bk = bk * z_beta[(size_t)zp++];
+        F.beta.push_back(bk * std::pow(sp.prior_scale[(size_t)k], (double)sp.num_normals[(size_t)k]) + sp.prior_mean[(size_t)k]);
+      }
     }
     theta_L(tp, aux, tau, zeta, rho, z_T, F.theta_L);
     make_b(tp, z_b, F.theta_L, F.b);
     F.constrained.clear();
     if (F.wantConstrained) {
     for (auto& x : z_beta) F.constrained.push_back(x);
+    for (auto& x : global) F.constrained.push_back(x);
+    for (int k = 0; k < (sp.hs ? sp.K : 0); ++k) for (int j = 0; j < sp.hs; ++j) F.constrained.push_back(local[(size_t)j][(size_t)k]);   // vector-index-major
+    for (auto& x : caux) F.constrained.push_back(x);
+    for (auto& x : mix) F.constrained.push_back(x);
+    for (auto& x : lambda1) F.constrained.push_back(x);
     for (auto& x : z_b) F.constrained.push_back(x);
     for (auto& x : z_T) F.constrained.push_back(x);
     for (auto& x : rho) F.constrained.push_back(x);
@@ -172,7 +215,28 @@ class HostModel {
         lp = lp + (tt + (std::lgamma((nu + 1.0) / 2.0) - std::lgamma(nu / 2.0) - 0.5 * std::log(nu * M_PI))) - log_half;
       } else lp = lp - aux_unscaled;
     }
-    if (sp.prior_dist == 1 || sp.prior_dist == 2) for (auto& z : z_beta) lp = lp + tstd_normal_lpdf(z);
+    if (sp.prior_dist >= 1) for (auto& z : z_beta) lp = lp + tstd_normal_lpdf(z);
+    {
+      const double log_half = -0.693147180559945286;
+      auto half_normal = [&](const std::vector<TV>& v) { for (auto& x : v) lp = lp + tstd_normal_lpdf(x); lp = lp - log_half; };
+      auto inv_gamma = [&](TV x, double al, double be) { lp = lp + (tlog(x) * (-(al + 1.0)) - (1.0 / x) * be + (al * std::log(be) - std::lgamma(al))); };
+      if (sp.hs > 0) {
+        half_normal(local[0]);
+        for (int k = 0; k < sp.K; ++k) inv_gamma(local[1][(size_t)k], 0.5 * sp.prior_df[(size_t)k], 0.5 * sp.prior_df[(size_t)k]);
+        if (sp.hs == 4) {
+          half_normal(local[2]);
+          for (int k = 0; k < sp.K; ++k) inv_gamma(local[3][(size_t)k], 0.5 * sp.prior_scale[(size_t)k], 0.5 * sp.prior_scale[(size_t)k]);
+        }
+        lp = lp + tstd_normal_lpdf(global[0]) - log_half;
+        inv_gamma(global[1], 0.5 * sp.global_prior_df, 0.5 * sp.global_prior_df);
+        inv_gamma(caux[0], 0.5 * sp.slab_df, 0.5 * sp.slab_df);
+      }
+      for (auto& x : mix) lp = lp - x;   // exponential_lpdf(mix | 1)
+      if (sp.n_lambda) {                 // chi_square_lpdf(one_over_lambda | prior_df[1])
+        double nu = sp.prior_df[0];
+        lp = lp + (tlog(lambda1[0]) * (0.5 * nu - 1.0) - lambda1[0] * 0.5 - (0.5 * nu * std::log(2.0) + std::lgamma(0.5 * nu)));
+      }
+    }
     for (auto& z : z_b) lp = lp + tstd_normal_lpdf(z);
     for (auto& z : z_T) lp = lp + tstd_normal_lpdf(z);
     int pos_reg = 0, pos_rho = 0;

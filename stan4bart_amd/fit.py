@@ -105,14 +105,37 @@ def make_sampler_args(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_tes
     Xc, xbar = center_x(X if X is not None else np.zeros((n, 0)))
     K = Xc.shape[1]
 
-    # priors (reference R/stan4bart_fit.R:100-232): normal(0, 2.5, autoscale), exponential(1, autoscale)
-    prior_scale = np.full(K, float(stan_args.get("prior_scale", 2.5)))
+    # priors (reference R/stan4bart_fit.R:100-232 + rstanarm handle_glm_prior): default normal(0, 2.5, autoscale) for
+    # the coefficients, exponential(1, autoscale) for sigma.  stan_args["prior"] = dict(dist=..., ...) selects another
+    # family with rstanarm's defaults: student_t(df=1) / hs(df=1, global_df=1, global_scale=0.01, slab_df=4,
+    # slab_scale=2.5) / hs_plus(df1=1, df2=1, ...) / laplace / lasso(df=1) / product_normal(df=2, scale=1)
+    prior = dict(stan_args.get("prior") or {})
+    dist = prior.get("dist", "normal")
+    dists = {"none": 0, "normal": 1, "student_t": 2, "hs": 3, "hs_plus": 4, "laplace": 5, "lasso": 6, "product_normal": 7}
+    if dist not in dists:
+        raise ValueError(f"prior dist must be one of {sorted(dists)}")
+    prior_dist = dists[dist]
+    autoscale = bool(prior.get("autoscale", dist in ("normal", "student_t", "laplace", "lasso")))
+    default_scale = 1.0 if dist == "product_normal" else float(stan_args.get("prior_scale", 2.5))
+    prior_scale = np.full(K, float(prior.get("scale", default_scale)))
+    prior_mean = np.full(K, float(prior.get("location", 0.0)))
+    prior_df = np.full(K, float(prior.get("df", prior.get("df1", 1.0))))
+    num_normals = None
+    hs_args = dict(global_prior_df=float(prior.get("global_df", 1.0)), global_prior_scale=float(prior.get("global_scale", 0.01)),
+                   slab_df=float(prior.get("slab_df", 4.0)), slab_scale=float(prior.get("slab_scale", 2.5)))
+    if dist == "hs_plus":
+        prior_scale = np.full(K, float(prior.get("df2", 1.0)))      # "unorthodox usage of prior_scale as another df" (continuous.stan:396)
+    if dist == "product_normal":
+        num_normals = np.full(K, int(prior.get("df", 2)), dtype=np.int32)
+        if np.any(num_normals < 2):
+            raise ValueError("product_normal needs df >= 2")
     ss = float(np.std(y, ddof=1)) if not is_binary else 1.0
-    if not is_binary:
-        prior_scale = ss * prior_scale
-    for k in range(K):
-        xs = 1.0 if len(np.unique(Xc[:, k])) == 1 else float(np.std(Xc[:, k], ddof=1))
-        prior_scale[k] = max(1e-12, prior_scale[k] / xs)
+    if prior_dist > 0 and autoscale:
+        if not is_binary:
+            prior_scale = ss * prior_scale
+        for k in range(K):
+            xs = 1.0 if len(np.unique(Xc[:, k])) == 1 else float(np.std(Xc[:, k], ddof=1))
+            prior_scale[k] = max(1e-12, prior_scale[k] / xs)
     prior_scale_for_aux = 0.0 if is_binary else ss * 1.0
 
     terms, p, l, w, v, u, q = make_z_csr(groups, n) if len(groups) else ([], [], [], np.zeros(0), np.zeros(0, np.int32),
@@ -136,8 +159,8 @@ def make_sampler_args(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_tes
         base=float(bart_args.get("base", 0.95)), power=float(bart_args.get("power", 2.0)),
         k=float(bart_args.get("k", 2.0)), keep_trees=bool(bart_args.get("keepTrees", False)),
         node_scale=3.0 if is_binary else 0.5,
-        X=Xc, y=y, weights=weights, is_binary=is_binary, prior_dist=1, prior_dist_for_aux=0 if is_binary else 3,
-        prior_scale=prior_scale, prior_mean=np.zeros(K), prior_df=np.ones(K),
+        X=Xc, y=y, weights=weights, is_binary=is_binary, prior_dist=prior_dist, prior_dist_for_aux=0 if is_binary else 3,
+        prior_scale=prior_scale, prior_mean=prior_mean, prior_df=prior_df, num_normals=num_normals, **hs_args,
         prior_scale_for_aux=prior_scale_for_aux, prior_mean_for_aux=0.0, prior_df_for_aux=1.0,
         p=p, l=l, shape=[float(decov["shape"])] * t, scale=[float(decov["scale"])] * t,
         concentration=[float(decov["concentration"])] * n_conc, regularization=[float(decov["regularization"])] * n_reg,
