@@ -174,6 +174,15 @@ int S4B_FN(get_stan_par_names)(s4b_sampler* s, char* buf, size_t cap);
 int S4B_FN(get_trees)(s4b_sampler* s, int64_t cap, int32_t* tree, int32_t* n_obs, int32_t* var,
                       int32_t* split, double* value, int64_t* num_nodes);
 
+/* stan4bart_exportBARTState — src/init.cpp:409-416 (+ R/stan4bart_fit.R:572-580): the trees kept while sampling (keep_trees),
+ * the cut points and the response scales as one relocatable byte string, so that a chain fitted in another process can be
+ * predicted from.  Call with buf = NULL (or cap too small) to learn the size. */
+int S4B_FN(export_bart_state)(s4b_sampler* s, void* buf, int64_t cap, int64_t* size);
+
+/* stan4bart_createStoredBARTSampler — src/init.cpp:418-446: a sampler that only holds an exported state; it supports
+ * predict_bart, export_bart_state, get_dims and free, everything else fails with a message. */
+int S4B_FN(create_stored_bart_sampler)(const void* state, int64_t size, int32_t device, s4b_sampler** out);
+
 /* stan4bart_predictBART(storedSampler, x_test, offset_test = NULL) — src/init.cpp:354-403, with the rescaling of
  * R/generics.R:671-674 folded in: BART fit of every kept draw at new predictor rows, on the data scale (probit: the
  * latent scale).  Trees are kept for the non-warmup runs of a sampler created with bart_control.keep_trees = 1

@@ -45,6 +45,8 @@ struct s4b_sampler {
   std::vector<double> row;   // last written Stan sample row (x_curr)
   size_t n = 0;
   long treeUpdates = 0;
+  // stored sampler (orc_create_stored_bart_sampler): what predict needs, without a fit
+  bool stored = false; size_t storedP = 0; int storedT = 0; std::vector<int> storedNumCuts; std::vector<std::vector<double>> storedCuts;
 };
 
 static StanData convert(const s4b_stan_data& d) {
@@ -70,6 +72,19 @@ static StanData convert(const s4b_stan_data& d) {
   if (d.has_weights) s.weights.assign(d.weights, d.weights + d.N);
   s.offset_.assign(d.N, 0.0);
   return s;
+}
+
+namespace {
+struct Blob {
+  std::vector<unsigned char> b;
+  template <class T> void put(const T* p, size_t n) { const unsigned char* q = (const unsigned char*)p; b.insert(b.end(), q, q + n * sizeof(T)); }
+  template <class T> void one(T v) { put(&v, 1); }
+};
+struct BlobIn {
+  const unsigned char* p; size_t n, pos;
+  template <class T> void get(T* dst, size_t k) { if (pos + k * sizeof(T) > n) throw std::invalid_argument("exported state: truncated"); if (k) std::memcpy(dst, p + pos, k * sizeof(T)); pos += k * sizeof(T); }
+  template <class T> T one() { T v; get(&v, 1); return v; }
+};
 }
 
 extern "C" {
@@ -139,6 +154,7 @@ int orc_create(const s4b_bart_control* bc, const s4b_bart_data* bd, const s4b_st
 }
 
 int orc_run(s4b_sampler* sp, int32_t numIter, int32_t isWarmup, int32_t resultsType, s4b_results* out) {
+  if (sp->stored) { g_err = "this call needs a live sampler: a stored BART sampler only predicts"; return 1; }
   try {
     if (!sp) throw std::invalid_argument("run called on NULL sampler");
     if (numIter < 1) throw std::invalid_argument("num_iter must be >= 1");
@@ -208,6 +224,7 @@ int orc_run(s4b_sampler* sp, int32_t numIter, int32_t isWarmup, int32_t resultsT
 }
 
 int orc_disengage_adaptation(s4b_sampler* s) {
+  if (s->stored) { g_err = "this call needs a live sampler: a stored BART sampler only predicts"; return 1; }
   if (!s) { g_err = "disengageAdaptation called on NULL sampler"; return 1; }
   s->nuts->disengage_adaptation();
   return 0;
@@ -235,6 +252,7 @@ int orc_get_r_rng_state(s4b_sampler* s, uint32_t* st) { st[0] = (uint32_t)s->rrn
 int orc_set_r_rng_state(s4b_sampler* s, const uint32_t* st) { s->rrng.mti = (int)st[0]; std::memcpy(s->rrng.mt, st + 1, 624 * 4); return 0; }
 
 int orc_get_dims(s4b_sampler* s, int64_t d[5]) {
+  if (s->stored) { d[0] = 0; d[1] = 0; d[2] = 0; d[3] = (int64_t)s->storedP; d[4] = s->storedT; return 0; }
   d[0] = s->model->n_row; d[1] = (int64_t)s->n; d[2] = (int64_t)s->bart->nTest; d[3] = (int64_t)s->bart->p; d[4] = s->bart->cfg.numTrees;
   return 0;
 }
@@ -257,6 +275,7 @@ int orc_get_stan_par_names(s4b_sampler* s, char* buf, size_t cap) {
 }
 
 int orc_get_trees(s4b_sampler* s, int64_t cap, int32_t* tree, int32_t* n_obs, int32_t* var, int32_t* split, double* value, int64_t* num_nodes) {
+  if (s->stored) { g_err = "this call needs a live sampler: a stored BART sampler only predicts"; return 1; }
   int64_t cnt = 0;
   for (int t = 0; t < s->bart->cfg.numTrees; ++t) {
     std::vector<int32_t> st; std::vector<double> mu;
@@ -302,22 +321,23 @@ int orc_profile_sweep(s4b_sampler*, int32_t, double out[8]) { for (int i = 0; i 
 int orc_predict_bart(s4b_sampler* s, const double* x_test, int64_t n_test, double* out, int64_t* num_samples) {
   *num_samples = (int64_t)s->kept.size();
   if (!out) return 0;
-  const BartFit& f = *s->bart;
-  std::vector<uint16_t> xb((size_t)f.p * (size_t)n_test);
-  for (size_t j = 0; j < f.p; ++j) for (int64_t i = 0; i < n_test; ++i) {
-    int c = 0; while (c < f.numCuts[j] && x_test[j * (size_t)n_test + i] > f.cuts[j][(size_t)c]) ++c;
+  const size_t P = s->stored ? s->storedP : s->bart->p;
+  const int T = s->stored ? s->storedT : s->bart->cfg.numTrees;
+  const std::vector<int>& numCuts = s->stored ? s->storedNumCuts : s->bart->numCuts;
+  const std::vector<std::vector<double>>& cuts = s->stored ? s->storedCuts : s->bart->cuts;
+  std::vector<uint16_t> xb(P * (size_t)n_test);
+  for (size_t j = 0; j < P; ++j) for (int64_t i = 0; i < n_test; ++i) {
+    int c = 0; while (c < numCuts[j] && x_test[j * (size_t)n_test + i] > cuts[j][(size_t)c]) ++c;
     xb[j * (size_t)n_test + i] = (uint16_t)c;
   }
   for (size_t k = 0; k < s->kept.size(); ++k) {
     const KeptSample& ks = s->kept[k];
     for (int64_t i = 0; i < n_test; ++i) {
       double fit = 0.0;
-      size_t pos = 0, leaf = 0;
-      for (int t = 0; t < f.cfg.numTrees; ++t) {
-        // walk the preorder serialisation of tree t: (var, split) pairs, leaves as (-1, count)
-        size_t start = ks.treeStart[(size_t)t], lstart = ks.leafStart[(size_t)t];
-        pos = start; leaf = lstart;
-        // descend: at an internal node go to the left child (next entry) or skip the left subtree
+      for (int t = 0; t < T; ++t) {
+        // walk the preorder serialisation of tree t: (var, split) pairs, leaves as (-1, count);
+        // at an internal node go to the left child (next entry) or skip the left subtree
+        size_t pos = ks.treeStart[(size_t)t], leaf = ks.leafStart[(size_t)t];
         while (ks.st[2 * pos] >= 0) {
           bool right = (int)xb[(size_t)ks.st[2 * pos] * (size_t)n_test + i] > ks.st[2 * pos + 1];
           ++pos;
@@ -329,6 +349,50 @@ int orc_predict_bart(s4b_sampler* s, const double* x_test, int64_t n_test, doubl
     }
   }
   return 0;
+}
+
+// exportBARTState / createStoredBARTSampler (reference src/init.cpp:409-446): the oracle's own byte layout
+int orc_export_bart_state(s4b_sampler* s, void* buf, int64_t cap, int64_t* size) {
+  try {
+    Blob o;
+    const size_t P = s->stored ? s->storedP : s->bart->p;
+    const int T = s->stored ? s->storedT : s->bart->cfg.numTrees;
+    const std::vector<int>& numCuts = s->stored ? s->storedNumCuts : s->bart->numCuts;
+    const std::vector<std::vector<double>>& cuts = s->stored ? s->storedCuts : s->bart->cuts;
+    o.one<uint32_t>(0x5343524fu); o.one<uint64_t>(P); o.one<int32_t>(T); o.one<int32_t>(s->binary ? 1 : 0); o.one<uint64_t>(s->kept.size());
+    for (size_t j = 0; j < P; ++j) { o.one<int32_t>(numCuts[j]); o.put(cuts[j].data(), (size_t)numCuts[j]); }
+    for (const KeptSample& k : s->kept) {
+      o.one<double>(k.min); o.one<double>(k.range);
+      o.one<uint64_t>(k.st.size()); o.put(k.st.data(), k.st.size());
+      o.one<uint64_t>(k.mu.size()); o.put(k.mu.data(), k.mu.size());
+      for (int t = 0; t < T; ++t) { o.one<uint64_t>(k.treeStart[(size_t)t]); o.one<uint64_t>(k.leafStart[(size_t)t]); }
+    }
+    *size = (int64_t)o.b.size();
+    if (buf && cap >= *size) std::memcpy(buf, o.b.data(), o.b.size());
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+int orc_create_stored_bart_sampler(const void* state, int64_t size, int32_t, s4b_sampler** out) {
+  try {
+    BlobIn in{(const unsigned char*)state, (size_t)(size < 0 ? 0 : size), 0};
+    if (!state || in.one<uint32_t>() != 0x5343524fu) throw std::invalid_argument("not an exported oracle BART state");
+    std::unique_ptr<s4b_sampler> s(new s4b_sampler());
+    s->stored = true;
+    s->storedP = (size_t)in.one<uint64_t>(); s->storedT = in.one<int32_t>(); s->binary = in.one<int32_t>() != 0;
+    const size_t S = (size_t)in.one<uint64_t>();
+    s->storedNumCuts.resize(s->storedP); s->storedCuts.resize(s->storedP);
+    for (size_t j = 0; j < s->storedP; ++j) { s->storedNumCuts[j] = in.one<int32_t>(); s->storedCuts[j].resize((size_t)s->storedNumCuts[j]); in.get(s->storedCuts[j].data(), s->storedCuts[j].size()); }
+    s->kept.resize(S);
+    for (KeptSample& k : s->kept) {
+      k.min = in.one<double>(); k.range = in.one<double>();
+      k.st.resize((size_t)in.one<uint64_t>()); in.get(k.st.data(), k.st.size());
+      k.mu.resize((size_t)in.one<uint64_t>()); in.get(k.mu.data(), k.mu.size());
+      k.treeStart.resize((size_t)s->storedT); k.leafStart.resize((size_t)s->storedT);
+      for (int t = 0; t < s->storedT; ++t) { k.treeStart[(size_t)t] = (size_t)in.one<uint64_t>(); k.leafStart[(size_t)t] = (size_t)in.one<uint64_t>(); }
+    }
+    *out = s.release();
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 void orc_free(s4b_sampler* s) { delete s; }
 

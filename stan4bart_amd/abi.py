@@ -253,7 +253,8 @@ class Sampler:
     def _bind(self):
         for name in ("create", "run", "disengage_adaptation", "print_initial_summary", "get_parametric_mean",
                      "get_bart_data_range", "get_r_rng_state", "set_r_rng_state", "get_dims", "get_stan_par_names",
-                     "get_trees", "set_trace", "get_trace", "get_leaf_assignment", "get_counters", "profile_sweep", "predict_bart"):
+                     "get_trees", "set_trace", "get_trace", "get_leaf_assignment", "get_counters", "profile_sweep", "predict_bart",
+                     "export_bart_state", "create_stored_bart_sampler"):
             getattr(self._lib, self._pfx + name).restype = C.c_int
         getattr(self._lib, self._pfx + "last_error").restype = C.c_char_p
         getattr(self._lib, self._pfx + "free").restype = None
@@ -364,6 +365,14 @@ class Sampler:
             self._check(self._f("predict_bart")(self._h, _dp(xt), xt.shape[0], _dp(out), C.byref(ns)))
         return out
 
+    def export_bart_state(self) -> bytes:
+        """``stan4bart_exportBARTState``: the kept trees + cut points + scales as one byte string."""
+        size = C.c_int64()
+        self._check(self._f("export_bart_state")(self._h, None, 0, C.byref(size)))
+        buf = C.create_string_buffer(size.value)
+        self._check(self._f("export_bart_state")(self._h, buf, size.value, C.byref(size)))
+        return buf.raw[: size.value]
+
     def profile_sweep(self, n_sweeps: int = 1) -> dict:
         """Extra BART sweeps timed with HIP events on the sampler's stream (measurement hook of the HIP library)."""
         out = (C.c_double * 8)()
@@ -375,6 +384,33 @@ class Sampler:
         if getattr(self, "_h", None) and self._h.value:
             self._f("free")(self._h)
             self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class StoredSampler:
+    """``stan4bart_createStoredBARTSampler`` (reference src/init.cpp:418-446, R/stan4bart_fit.R:572-580): a sampler rebuilt
+    from an exported BART state — in another process, after the fitting sampler is gone — that predicts from the kept trees."""
+
+    def __init__(self, lib: C.CDLL, prefix: str, state: bytes, device: int = 0):
+        self._lib, self._pfx = lib, prefix
+        self._h = C.c_void_p()
+        Sampler._bind(self)
+        buf = C.create_string_buffer(state, len(state))
+        self._check(self._f("create_stored_bart_sampler")(buf, C.c_int64(len(state)), C.c_int32(device), C.byref(self._h)))
+
+    _f = Sampler._f
+    _check = Sampler._check
+    predict_bart = Sampler.predict_bart
+    export_bart_state = Sampler.export_bart_state
+    free = Sampler.free
+
+    def get_trees(self):
+        raise ValueError("a stored BART sampler only predicts")
 
     def __del__(self):
         try:

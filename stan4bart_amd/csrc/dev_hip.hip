@@ -1109,6 +1109,18 @@ class DevHip {
   }
   DevHip(const DevHip&) = delete;
 
+  // stored sampler: only a device, a stream and the predictor count (predict_stored needs nothing else)
+  void init_stored(int device, int P) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+      throw std::runtime_error("stan4bart_amd: no HIP device available — the MI355X path has no CPU fallback");
+    if (device < 0 || device >= count) throw std::runtime_error("stan4bart_amd: HIP device ordinal out of range");
+    device_ = device;
+    HIP_OK(hipSetDevice(device_));
+    HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    a_ = BartArrays{}; a_.P = P; P_ = P;
+  }
   void init(const DevInit& d) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);

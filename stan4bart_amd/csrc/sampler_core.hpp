@@ -50,6 +50,43 @@ struct DevInit {
 template <class Dev>
 class SamplerCore {
  public:
+  // stored sampler (stan4bart_createStoredBARTSampler, reference src/init.cpp:418-446): only the exported kept trees
+  SamplerCore(const void* state, int64_t size, int device) {
+    stored_ = true;
+    Reader r{(const unsigned char*)state, (size_t)(size < 0 ? 0 : size), 0};
+    if (!state || r.u32() != STATE_MAGIC) throw std::invalid_argument("not an exported stan4bart_amd BART state");
+    if (r.u32() != 1u) throw std::invalid_argument("exported BART state: unknown version");
+    P_ = (int)r.u32(); T_ = (int)r.u32(); binary_ = r.u32() != 0;
+    const uint64_t S = r.u64(), numNodes = r.u64();
+    if (P_ < 1 || T_ < 1) throw std::invalid_argument("exported BART state: bad dimensions");
+    numCuts_.resize((size_t)P_); r.get(numCuts_.data(), (size_t)P_ * 4);
+    cuts_.resize((size_t)P_);
+    for (int j = 0; j < P_; ++j) { if (numCuts_[(size_t)j] < 0 || numCuts_[(size_t)j] > 65534) throw std::invalid_argument("exported BART state: bad cut count");
+                                   cuts_[(size_t)j].resize((size_t)numCuts_[(size_t)j]); r.get(cuts_[(size_t)j].data(), cuts_[(size_t)j].size() * 8); }
+    keptScale_.resize((size_t)S * 2); r.get(keptScale_.data(), keptScale_.size() * 8);
+    keptTreeStart_.resize((size_t)S * (size_t)T_); r.get(keptTreeStart_.data(), keptTreeStart_.size() * 8);
+    keptNodes_.resize((size_t)numNodes); r.get(keptNodes_.data(), keptNodes_.size() * sizeof(PackedNode));
+    for (int64_t st : keptTreeStart_) if (st < 0 || (uint64_t)st >= numNodes) throw std::invalid_argument("exported BART state: tree offset out of range");
+    for (const PackedNode& nd : keptNodes_) if (nd.var >= P_) throw std::invalid_argument("exported BART state: predictor index out of range");
+    dev_.init_stored(device, P_);
+  }
+  // stan4bart_exportBARTState (reference src/init.cpp:409-416): needed size; written when the buffer is large enough
+  int64_t export_state(void* buf, int64_t cap) const {
+    size_t need = 4 * 5 + 8 * 2 + (size_t)P_ * 4;
+    for (int j = 0; j < P_; ++j) need += cuts_[(size_t)j].size() * 8;
+    need += keptScale_.size() * 8 + keptTreeStart_.size() * 8 + keptNodes_.size() * sizeof(PackedNode);
+    if (!buf || cap < (int64_t)need) return (int64_t)need;
+    unsigned char* o = (unsigned char*)buf;
+    auto put = [&](const void* src, size_t n) { if (n) std::memcpy(o, src, n); o += n; };
+    const uint32_t head[5] = {STATE_MAGIC, 1u, (uint32_t)P_, (uint32_t)T_, binary_ ? 1u : 0u};
+    const uint64_t cnt[2] = {(uint64_t)keptScale_.size() / 2, (uint64_t)keptNodes_.size()};
+    put(head, sizeof(head)); put(cnt, sizeof(cnt)); put(numCuts_.data(), (size_t)P_ * 4);
+    for (int j = 0; j < P_; ++j) put(cuts_[(size_t)j].data(), cuts_[(size_t)j].size() * 8);
+    put(keptScale_.data(), keptScale_.size() * 8); put(keptTreeStart_.data(), keptTreeStart_.size() * 8);
+    put(keptNodes_.data(), keptNodes_.size() * sizeof(PackedNode));
+    return (int64_t)need;
+  }
+
   SamplerCore(const s4b_bart_control* bc, const s4b_bart_data* bd, const s4b_stan_data* sd, const s4b_stan_control* sc,
               const s4b_common_control* cc, const uint32_t* rstate) {
     if (!bc || !bd || !sd || !sc || !cc || !rstate) throw std::invalid_argument("create: NULL argument");
@@ -168,6 +205,7 @@ class SamplerCore {
 
   // stan4bart_run (reference src/init.cpp:678-965)
   void run(int numIter, bool isWarmup, int resultsType, s4b_results* out) {
+    live();
     if (numIter < 1) throw std::invalid_argument("num_iter must be >= 1");
     const bool doStan = resultsType == 0 || resultsType == 2, doBart = resultsType == 0 || resultsType == 1;
     const int numPars = (int)row_.size();
@@ -228,17 +266,19 @@ class SamplerCore {
     check_device();
   }
 
-  void disengage_adaptation() { nuts_->disengage(); }
+  void disengage_adaptation() { live(); nuts_->disengage(); }
 
   void parametric_mean(double* out) {
+    live();
     const double* cons = row_.data() + 7;
     dev_.param_mean_to_host(cons + model_->sp.beta_pos(), cons + model_->sp.b_pos(), out);
   }
-  void data_range(double out[2]) { ScaleState s; dev_.get_scale(s); out[0] = s.min; out[1] = s.max; }
-  void get_rng(uint32_t* st) { dev_.download_rng(rng_); st[0] = (uint32_t)rng_.mti; std::memcpy(st + 1, rng_.mt, 624 * 4); }
-  void set_rng(const uint32_t* st) { rng_.mti = (int32_t)st[0]; rng_.pad = 0; std::memcpy(rng_.mt, st + 1, 624 * 4); dev_.upload_rng(rng_); }
+  void data_range(double out[2]) { live(); ScaleState s; dev_.get_scale(s); out[0] = s.min; out[1] = s.max; }
+  void get_rng(uint32_t* st) { live(); dev_.download_rng(rng_); st[0] = (uint32_t)rng_.mti; std::memcpy(st + 1, rng_.mt, 624 * 4); }
+  void set_rng(const uint32_t* st) { live(); rng_.mti = (int32_t)st[0]; rng_.pad = 0; std::memcpy(rng_.mt, st + 1, 624 * 4); dev_.upload_rng(rng_); }
   void dims(int64_t d[5]) { d[0] = (int64_t)row_.size(); d[1] = (int64_t)n_; d[2] = (int64_t)nTest_; d[3] = P_; d[4] = T_; }
   std::string par_names() const {
+    live();
     const StanSpec& m = model_->sp;
     std::string o = "lp__\naccept_stat__\nstepsize__\ntreedepth__\nn_leapfrog__\ndivergent__\nenergy__";
     auto add = [&](const char* base, int cnt) { for (int i = 1; i <= cnt; ++i) o += "\n" + std::string(base) + "." + std::to_string(i); };
@@ -253,12 +293,14 @@ class SamplerCore {
     return o;
   }
   void print_summary() const {
+    live();
     std::printf("stan4bart_amd sampler: n = %zu, p = %d, trees = %d, node capacity = %d, unconstrained stan params = %d, hmc mode = %s\n",
                 n_, P_, T_, nc_, model_->sp.D, hmcMode_ == 0 ? "sufficient statistics" : "per-leapfrog kernels");
   }
 
   // flattened live trees, preorder (stan4bart_getTrees layout; reference src/init.cpp:583-665)
   int64_t get_trees(int64_t cap, int32_t* tree, int32_t* n_obs, int32_t* var, int32_t* split, double* value) {
+    live();
     HostTrees h; download_trees(h);
     int64_t cnt = 0;
     for (int t = 0; t < T_; ++t) {
@@ -290,9 +332,10 @@ class SamplerCore {
     dev_.predict_stored(xb.data(), nT, keptNodes_.data(), keptNodes_.size(), keptTreeStart_.data(), S, T_, keptScale_.data(), binary_ ? 1 : 0, out);
     return S;
   }
-  void set_trace(bool on) { dev_.set_trace(on); }
-  int64_t get_trace(int64_t cap, int32_t* out) { return dev_.get_trace(cap, out); }
+  void set_trace(bool on) { live(); dev_.set_trace(on); }
+  int64_t get_trace(int64_t cap, int32_t* out) { live(); return dev_.get_trace(cap, out); }
   void leaf_assignment(int t, int32_t* out) {
+    live();
     if (t < 0 || t >= T_) throw std::invalid_argument("tree index out of range");
     HostTrees h; download_trees(h);
     TreeView tv = h.view(t, nc_);
@@ -304,11 +347,20 @@ class SamplerCore {
     dev_.download_leaf_plane(t, leaf.data());
     for (size_t i = 0; i < n_; ++i) out[i] = rank[leaf[i]];
   }
-  void profile_sweep(int nSweeps, double out[8]) { if (nSweeps < 1) throw std::invalid_argument("n_sweeps must be >= 1"); dev_.profile_sweep(nSweeps, thin_, out); out[7] = (double)n_; check_device(); }
-  void counters(int64_t out[3]) { out[0] = model_->gradEvals; out[1] = treeUpdates_; out[2] = dev_.launches(); }
+  void profile_sweep(int nSweeps, double out[8]) { live(); if (nSweeps < 1) throw std::invalid_argument("n_sweeps must be >= 1"); dev_.profile_sweep(nSweeps, thin_, out); out[7] = (double)n_; check_device(); }
+  void counters(int64_t out[3]) { live(); out[0] = model_->gradEvals; out[1] = treeUpdates_; out[2] = dev_.launches(); }
   Dev& dev() { return dev_; }
 
  private:
+  static constexpr uint32_t STATE_MAGIC = 0x54423453u;   // "S4BT"
+  struct Reader {
+    const unsigned char* p; size_t n, pos;
+    void get(void* dst, size_t k) { if (pos + k > n) throw std::invalid_argument("exported BART state: truncated"); if (k) std::memcpy(dst, p + pos, k); pos += k; }
+    uint32_t u32() { uint32_t v; get(&v, 4); return v; }
+    uint64_t u64() { uint64_t v; get(&v, 8); return v; }
+  };
+  bool stored_ = false;
+  void live() const { if (stored_) throw std::invalid_argument("this call needs a live sampler: a stored BART sampler only predicts"); }
   struct HostTrees {
     std::vector<int16_t> var, left, right, parent, na, dep; std::vector<uint16_t> cut; std::vector<double> mu; std::vector<int32_t> cnt, hwm;
     TreeView view(int t, int nc) { size_t o = (size_t)t * nc; return make_tree_view(var.data() + o, cut.data() + o, left.data() + o, right.data() + o, parent.data() + o, nc, na.data(), dep.data()); }

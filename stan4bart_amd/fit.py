@@ -192,6 +192,7 @@ def fit_worker(make_sampler: Callable[[SamplerArgs, np.ndarray], Sampler], args:
         results["range.bart"] = sampler.get_bart_data_range()
         if args.keep_trees:
             results["trees"] = sampler.get_trees()
+            results["bart_state"] = sampler.export_bart_state()   # exportBARTState: survives the sampler (R/stan4bart_fit.R:572-580)
         rng.state = sampler.get_r_rng_state()
     finally:
         sampler.free()

@@ -289,6 +289,22 @@ class Stan4bartFit:
                 result = result + rng.standard_normal(result.shape) * sig[None]
         return combine_chains_f(result) if combine_chains else result
 
+    def export_bart_states(self) -> list:
+        """``stan4bart_exportBARTState`` per chain (reference R/stan4bart_fit.R:572-580): byte strings that
+        ``attach_stored_samplers`` turns back into predict-capable samplers, in this or another process."""
+        if not self.samplers:
+            raise ValueError("exporting the BART state requires bart_args keepTrees")
+        return [s.export_bart_state() for s in self.samplers]
+
+    def attach_stored_samplers(self, states: Sequence[bytes], lib=None, prefix: str = "s4b_", device: int = 0):
+        """``stan4bart_createStoredBARTSampler`` for every chain: afterwards ``predict`` works without the fitting samplers."""
+        from .abi import StoredSampler
+        if lib is None:
+            from ._lib import load_library
+            lib = load_library()
+        self.close()
+        self.samplers = [StoredSampler(lib, prefix, st, device) for st in states]
+
     def close(self):
         for s in self.samplers:
             s.free()

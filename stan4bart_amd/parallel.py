@@ -64,7 +64,15 @@ def run_chains_distributed(make_sampler: Callable, seed: int, y, x_bart, **kw) -
     res = fit_worker(make_sampler, args, rng)
     draws = np.stack(all_gather_array(res["sample"]["stan"]))
     sigma_mean = np.stack(all_gather_array(np.array([res["sample"]["bart"]["sigma"].mean()])))
-    return dict(local=res, stan=draws, sigma_mean=sigma_mean[:, 0], rhat=split_rhat(draws), par_names=res["par_names"])
+    out = dict(local=res, stan=draws, sigma_mean=sigma_mean[:, 0], rhat=split_rhat(draws), par_names=res["par_names"])
+    if "bart_state" in res:   # the kept trees of every chain, as exported byte strings (any rank can rebuild predict-capable samplers)
+        states = [None] * world
+        if world > 1:
+            dist.all_gather_object(states, res["bart_state"])
+        else:
+            states = [res["bart_state"]]
+        out["bart_states"] = states
+    return out
 
 
 def split_rhat(draws: np.ndarray) -> np.ndarray:

@@ -15,6 +15,7 @@ namespace s4b {
 
 class DevCpu {
  public:
+  void init_stored(int, int P) { P_ = P; }
   void init(const DevInit& d) {
     di_ = d;
     n_ = (size_t)d.n; nTest_ = (size_t)d.nTest; P_ = d.P; T_ = d.T; nc_ = d.nc; K_ = d.K; q_ = d.q; binary_ = d.binary != 0;

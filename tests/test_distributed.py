@@ -26,7 +26,12 @@ def _worker(rank, world, port, tmpdir):
     x = d["x"]
     res = run_chains_distributed(lambda a, st: Sampler(lib, "emu_", a, st), 777, d["y"], x[:, [0, 1, 2, 4, 5, 6, 7, 8, 9]],
                                  X=np.column_stack([x[:, 3], d["z"]]), groups=[GroupTerm(d["g1"]), GroupTerm(d["g2"])],
-                                 iter=13, warmup=7, bart_args={"n.trees": 11})
+                                 iter=13, warmup=7, bart_args={"n.trees": 11, "keepTrees": True})
+    # every rank can predict from every chain's kept trees (exported, gathered, rebuilt as stored samplers)
+    from stan4bart_amd.abi import StoredSampler
+    preds = [StoredSampler(lib, "emu_", st).predict_bart(x[:5, [0, 1, 2, 4, 5, 6, 7, 8, 9]]) for st in res["bart_states"]]
+    np.save(os.path.join(tmpdir, f"pred_{rank}.npy"), np.stack(preds))
+    np.save(os.path.join(tmpdir, f"train_{rank}.npy"), res["local"]["sample"]["bart"]["train"][:5])
     np.save(os.path.join(tmpdir, f"stan_{rank}.npy"), res["stan"])
     np.save(os.path.join(tmpdir, f"local_{rank}.npy"), res["local"]["sample"]["stan"])
     dist.barrier()
@@ -45,6 +50,10 @@ def test_two_chains_two_ranks_gloo(emul_lib, tmp_path):
     for r in range(2):
         assert np.array_equal(g0[r], np.load(tmp_path / f"local_{r}.npy"))   # chain r came from rank r
     assert not np.array_equal(g0[0], g0[1])                                  # different seeds => different chains
+    p0, p1 = np.load(tmp_path / "pred_0.npy"), np.load(tmp_path / "pred_1.npy")
+    assert p0.shape == (2, 5, 6) and np.array_equal(p0, p1)                  # [chain, row, kept draw] on both ranks
+    for r in range(2):                                                       # predict(training rows) == training fit of chain r
+        np.testing.assert_allclose(p0[r], np.load(tmp_path / f"train_{r}.npy"), rtol=1e-9, atol=1e-9)
     # the same chains fitted serially with the same per-chain seeds are identical
     from stan4bart_amd import GroupTerm, RRng, generate_friedman_data, make_sampler_args, fit_worker
     from stan4bart_amd.abi import Sampler
@@ -54,7 +63,7 @@ def test_two_chains_two_ranks_gloo(emul_lib, tmp_path):
     for r in range(2):
         rng = RRng(int(chain_seeds(777, 2)[r]))
         args = make_sampler_args(d["y"], x[:, [0, 1, 2, 4, 5, 6, 7, 8, 9]], X=np.column_stack([x[:, 3], d["z"]]),
-                                 groups=[GroupTerm(d["g1"]), GroupTerm(d["g2"])], iter=13, warmup=7, bart_args={"n.trees": 11}, device=r)
+                                 groups=[GroupTerm(d["g1"]), GroupTerm(d["g2"])], iter=13, warmup=7, bart_args={"n.trees": 11, "keepTrees": True}, device=r)
         res = fit_worker(lambda a, st: Sampler(emul_lib, "emu_", a, st), args, rng)
         assert np.array_equal(res["sample"]["stan"], g0[r])
 

@@ -95,6 +95,47 @@ def test_generics_host_logic(emul_lib, binary):
     _check_surface(fit, data)
 
 
+def _check_stored(fit, data, lib, prefix):
+    """exportBARTState -> createStoredBARTSampler (reference src/init.cpp:409-446): predictions from the rebuilt samplers
+    are identical to those of the fitting samplers, which may be gone by then."""
+    d, xb, X, groups, rows, groups_t = data
+    before = {t: fit.predict(x_bart=xb[:23], X=X[:23], groups=[type(g)(np.asarray(g.levels)[:23], None if g.slopes is None else
+                             np.asarray(g.slopes)[:23], g.name) for g in groups], type=t, combine_chains=False) for t in ("ev", "indiv.bart")}
+    states = fit.export_bart_states()
+    assert all(isinstance(b, bytes) and len(b) > 64 for b in states)
+    fit.attach_stored_samplers(states, lib=lib, prefix=prefix)          # closes the live samplers
+    for t, ref in before.items():
+        got = fit.predict(x_bart=xb[:23], X=X[:23], groups=[type(g)(np.asarray(g.levels)[:23], None if g.slopes is None else
+                          np.asarray(g.slopes)[:23], g.name) for g in groups], type=t, combine_chains=False)
+        np.testing.assert_array_equal(got, ref)
+    assert fit.export_bart_states() == states                           # a stored sampler re-exports the same bytes
+    with pytest.raises((RuntimeError, ValueError), match="stored|only predicts"):
+        fit.extract("trees")
+    from stan4bart_amd.abi import StoredSampler
+    with pytest.raises(RuntimeError, match="exported|truncated"):
+        StoredSampler(lib, prefix, states[0][: len(states[0]) // 2])
+    with pytest.raises(RuntimeError, match="exported"):
+        StoredSampler(lib, prefix, b"\x00" * 64)
+    fit.close()
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_stored_sampler_host_logic(emul_lib, binary):
+    fit, data = _fit(emul_lib, "emu_", binary=binary)
+    _check_stored(fit, data, emul_lib, "emu_")
+
+
+def test_stored_sampler_oracle(oracle_lib):
+    fit, data = _fit(oracle_lib, "orc_")
+    _check_stored(fit, data, oracle_lib, "orc_")
+
+
+@pytest.mark.gpu
+def test_stored_sampler_on_hip(hip_lib):
+    fit, data = _fit(hip_lib, "s4b_")
+    _check_stored(fit, data, hip_lib, "s4b_")
+
+
 def test_predict_needs_kept_trees(emul_lib):
     fit, data = _fit(emul_lib, "emu_", keep_trees=False, chains=1)
     with pytest.raises(ValueError, match="keepTrees"):
