@@ -155,6 +155,7 @@ def main():
     sig = all_gather_array(np.array([float(out["bart"]["sigma"][-1])]))   # the only collective: chain summaries
 
     prof = sampler.profile_sweep(a.profile_sweeps) if rank == 0 else None
+    lf = sampler.profile_leapfrog(20) if rank == 0 else None
     sampler.free()
     del args
     target = None
@@ -194,6 +195,15 @@ def main():
                                          "achieved_GBs_incl_control": 22.0 * n / (tree_update_us * 1e-6) / 1e9},
                          "sweep_wall_us": prof["sweep_wall_us"]},
         }
+        # second kernel group of the path: the O(N) sums one leapfrog costs when the gradient is evaluated on the device
+        # (hmc_mode 1, the reference's cost model).  The timed region above uses hmc_mode 0, where a leapfrog is O((K+q)^2)
+        # on the host from sufficient statistics gathered once per Gibbs iteration by these same kernels.
+        rec["roofline_hmc"] = {"bound": "hbm", "kernel": "k_stan_inputs + k_zt_chunks + k_stan_finalize (direct)",
+                               "achieved": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                               "avg_eval_us": lf["kernels_us"], "avg_eval_us_with_result_fetch": lf["with_fetch_us"],
+                               "launches_per_eval": lf["launches"], "algorithmic_bytes_per_eval": lf["algorithmic_bytes"],
+                               "note": "N (8K + 12z + 20) bytes per leapfrog (SURVEY 8d B_lf); not in the timed region (hmc_mode 0)"}
         if target is not None:
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:

@@ -204,6 +204,10 @@ int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
  * {stats, control, apply}: out[0..2] = average launch duration in microseconds, out[3..5] = launches timed,
  * out[6] = wall microseconds per sweep (events around the whole sweep, no per-launch events), out[7] = n. */
 int S4B_FN(profile_sweep)(s4b_sampler* s, int32_t n_sweeps, double out[8]);
+/* extension (measurement): HIP-event timing of the per-leapfrog O(N) sums of the hmc_mode 1 path at the current draw.
+ * out[0] us per evaluation (kernels), out[1] us including the result fetch, out[2] launches per evaluation, out[3] N,
+ * out[4] algorithmic bytes per evaluation N (8K + 12z + 20) (SURVEY §8d B_lf) */
+int S4B_FN(profile_leapfrog)(s4b_sampler* s, int32_t n_evals, double out[8]);
 
 /* finalizer of the externalptr — src/init.cpp:1152-1165 */
 void S4B_FN(free)(s4b_sampler* s);

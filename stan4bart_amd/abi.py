@@ -254,7 +254,7 @@ class Sampler:
         for name in ("create", "run", "disengage_adaptation", "print_initial_summary", "get_parametric_mean",
                      "get_bart_data_range", "get_r_rng_state", "set_r_rng_state", "get_dims", "get_stan_par_names",
                      "get_trees", "set_trace", "get_trace", "get_leaf_assignment", "get_counters", "profile_sweep", "predict_bart",
-                     "export_bart_state", "create_stored_bart_sampler"):
+                     "export_bart_state", "create_stored_bart_sampler", "profile_leapfrog"):
             getattr(self._lib, self._pfx + name).restype = C.c_int
         getattr(self._lib, self._pfx + "last_error").restype = C.c_char_p
         getattr(self._lib, self._pfx + "free").restype = None
@@ -364,6 +364,12 @@ class Sampler:
         if ns.value:
             self._check(self._f("predict_bart")(self._h, _dp(xt), xt.shape[0], _dp(out), C.byref(ns)))
         return out
+
+    def profile_leapfrog(self, n_evals: int = 10) -> dict:
+        """Per-leapfrog O(N) sums of the hmc_mode 1 path timed with HIP events (measurement hook of the HIP library)."""
+        out = (C.c_double * 8)()
+        self._check(self._f("profile_leapfrog")(self._h, n_evals, out))
+        return dict(kernels_us=out[0], with_fetch_us=out[1], launches=out[2], n=int(out[3]), algorithmic_bytes=out[4])
 
     def export_bart_state(self) -> bytes:
         """``stan4bart_exportBARTState``: the kept trees + cut points + scales as one byte string."""

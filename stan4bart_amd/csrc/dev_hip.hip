@@ -14,6 +14,7 @@
 // the R-compatible random stream stay on the device (one lane of k_control), so a sweep over all
 // trees is a pure launch sequence with no host round trip.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <cstdio>
 #include <cstdlib>
@@ -1436,6 +1437,24 @@ class DevHip {
     return ss;
   }
 
+  // HIP-event timing of the per-leapfrog O(N) sums (hmc_mode 1 path: e = e0 - X beta - Z b, |e|^2, X'e, Z'e) on the
+  // sampler's stream.  out: [0] us per evaluation, kernels only; [1] us per evaluation including the result fetch;
+  // [2] kernel launches per evaluation
+  void profile_leapfrog(int nEvals, const double* beta, const double* b, double* out) {
+    push_params(beta, b);
+    reduce_pipeline(0, 0, 1); sync();                     // warm
+    const int64_t l0 = launches_;
+    HIP_OK(hipEventRecord(evStart_, stream_));
+    for (int i = 0; i < nEvals; ++i) reduce_pipeline(0, 0, 1);
+    HIP_OK(hipEventRecord(evStop_, stream_));
+    sync();
+    float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_));
+    out[0] = ms * 1000.0 / nEvals; out[2] = (double)(launches_ - l0) / nEvals;
+    std::vector<double> gX((size_t)K_ + 1), gZ((size_t)q_ + 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < nEvals; ++i) (void)leapfrog_sums(beta, b, gX.data(), gZ.data());
+    out[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6 / nEvals;
+  }
   // timing hook for bench.py: events on the stream the kernels are launched on
   hipStream_t stream() const { return stream_; }
   const BartArrays& arrays() const { return a_; }

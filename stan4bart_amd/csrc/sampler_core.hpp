@@ -165,7 +165,7 @@ class SamplerCore {
       di.model.pgDepth = pgDepth_.data(); di.model.logPg = logPg_.data(); di.model.log1mPg = log1mPg_.data();
       di.model.logInt = logInt_.data(); di.model.logIntLen = (int32_t)logInt_.size();
     }
-    di.K = K_; di.q = q_; di.binary = binary_ ? 1 : 0; di.X = sd->X; di.w = sd->w; di.v = sd->v; di.u = sd->u; di.nnz = sd->num_non_zero;
+    di.K = K_; di.q = q_; di.binary = binary_ ? 1 : 0; di.X = sd->X; di.w = sd->w; di.v = sd->v; di.u = sd->u; di.nnz = sd->num_non_zero; nnz_ = sd->num_non_zero;
     di.traceCap = 1 << 16;
     hostModelView_ = di.model; hostModelView_.numCuts = numCuts_.data();   // (table pointers are host pointers)
     dev_.init(di);
@@ -348,6 +348,18 @@ class SamplerCore {
     for (size_t i = 0; i < n_; ++i) out[i] = rank[leaf[i]];
   }
   void profile_sweep(int nSweeps, double out[8]) { live(); if (nSweeps < 1) throw std::invalid_argument("n_sweeps must be >= 1"); dev_.profile_sweep(nSweeps, thin_, out); out[7] = (double)n_; check_device(); }
+  // measurement hook: the O(N) sums of one leapfrog on the device at the current draw; out[3] = N, out[4] = SURVEY §8d's
+  // algorithmic bytes per evaluation N (8K + 12z + 20), z = non-zeros of Z per row
+  void profile_leapfrog(int nEvals, double out[8]) {
+    live();
+    if (nEvals < 1) throw std::invalid_argument("n_evals must be >= 1");
+    const double* cons = row_.data() + 7;
+    for (int i = 0; i < 8; ++i) out[i] = 0.0;
+    dev_.profile_leapfrog(nEvals, cons + model_->sp.beta_pos(), cons + model_->sp.b_pos(), out);
+    const double z = n_ ? (double)nnz_ / (double)n_ : 0.0;
+    out[3] = (double)n_; out[4] = (double)n_ * (8.0 * K_ + 12.0 * z + 20.0);
+    check_device();
+  }
   void counters(int64_t out[3]) { live(); out[0] = model_->gradEvals; out[1] = treeUpdates_; out[2] = dev_.launches(); }
   Dev& dev() { return dev_; }
 
@@ -359,7 +371,7 @@ class SamplerCore {
     uint32_t u32() { uint32_t v; get(&v, 4); return v; }
     uint64_t u64() { uint64_t v; get(&v, 8); return v; }
   };
-  bool stored_ = false;
+  bool stored_ = false; int64_t nnz_ = 0;
   void live() const { if (stored_) throw std::invalid_argument("this call needs a live sampler: a stored BART sampler only predicts"); }
   struct HostTrees {
     std::vector<int16_t> var, left, right, parent, na, dep; std::vector<uint16_t> cut; std::vector<double> mu; std::vector<int32_t> cnt, hwm;
