@@ -70,7 +70,7 @@ class Stan4bartFit:
     range_bart: np.ndarray      # [2, chains] (min, max) of the BART response scale
     samplers: list = field(default_factory=list)   # live samplers holding the kept trees (bart_args keepTrees)
     trees: Optional[list] = None
-    callback: Optional[list] = None
+    callback: Optional[np.ndarray] = None   # [len(result), iterations, chains]
 
     # ------------------------------------------------------------------ helpers
     def _get(self, name: str, include_warmup, only_warmup):
@@ -177,7 +177,7 @@ class Stan4bartFit:
         if type == "callback":
             if self.callback is None:
                 raise ValueError("cannot extract callback samples for model fit without callback function")
-            return self.callback
+            return done(self._get("callback", include_warmup, only_warmup))
         is_bernoulli = self.family == "binomial"
         if type == "sigma" and is_bernoulli:
             raise ValueError("cannot extract 'sigma': binary outcome model does not have a residual standard error parameter")
@@ -322,12 +322,38 @@ def _stack(chain_results, phase, key, sub=None):
 def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=None, X_test=None,
               groups_test: Optional[Sequence[GroupTerm]] = None, offset=None, offset_test=None, offset_type: str = "default",
               family: str = "gaussian", chains: int = 4, seed: Optional[int] = None, iter: int = 2000, warmup: int = 1000,
-              keep_warmup: bool = True, make_sampler: Optional[Callable] = None, **kw) -> Stan4bartFit:
+              keep_warmup: bool = True, make_sampler: Optional[Callable] = None, treatment=None, callback: Optional[Callable] = None,
+              **kw) -> Stan4bartFit:
     """The reference's ``stan4bart()`` after its formula front end (R/stan4bart.R:1-297 -> arrays): runs ``chains``
     chains with the single-threaded seeding rule (R/stan4bart_fit.R:545-554) and packages the draws
     (``package_samples``, R/stan4bart.R:299-455).  With ``bart_args = {"keepTrees": True}`` the samplers stay alive
-    inside the fit (``object$sampler.bart``) so that ``predict`` can use the kept trees; call ``close()`` when done."""
+    inside the fit (``object$sampler.bart``) so that ``predict`` can use the kept trees; call ``close()`` when done.
+
+    ``treatment = ("X" | "x_bart", column)`` names a binary treatment column: the test sample becomes the training rows
+    with the treatment flipped, i.e. the counterfactual (reference R/stan4bart.R:93-120, tests/testthat/test-10-treatment.R).
+    ``callback(yhat_train, yhat_test, stan_pars, par_names)`` is evaluated after every iteration inside the sampler
+    (reference src/init.cpp:849-911, tests/testthat/test-11-callback.R); its results come back as ``extract("callback")``."""
     make_sampler = make_sampler or hip_sampler_factory()
+    if treatment is not None:
+        if x_bart_test is not None or X_test is not None:
+            raise ValueError("'treatment' builds the test sample itself: do not pass test data as well")
+        where, col = treatment
+        if where not in ("X", "x_bart"):
+            raise ValueError("treatment must be ('X', column) or ('x_bart', column)")
+        src = np.asarray(X if where == "X" else x_bart, dtype=np.float64)
+        vals = np.unique(src[:, col])
+        if len(vals) != 2:
+            raise ValueError("treatment must be binary")
+        flipped = src.copy()
+        flipped[:, col] = np.where(src[:, col] == vals[0], vals[1], vals[0])
+        x_bart_test = flipped if where == "x_bart" else np.asarray(x_bart, dtype=np.float64)
+        X_test = flipped if where == "X" else (None if X is None else np.asarray(X, dtype=np.float64))
+        groups_test = list(groups) if len(groups) else None
+        offset_test = offset
+    names_box: list = []
+    cb = None
+    if callback is not None:
+        cb = lambda tr, te, sp: np.asarray(callback(tr, te, sp, names_box[0]), dtype=np.float64)
     import os
     rng = RRng(seed if seed is not None else int.from_bytes(os.urandom(4), "little") % INT_MAX)
     keep_trees = bool((kw.get("bart_args") or {}).get("keepTrees", False))
@@ -335,11 +361,12 @@ def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=N
     args = None
     for _ in range(chains):
         args = make_sampler_args(y, x_bart, X=X, groups=groups, x_test=x_bart_test, family=family, iter=iter, warmup=warmup,
-                                 offset=offset, offset_type=offset_type, keep_fits=True, **kw)
+                                 offset=offset, offset_type=offset_type, keep_fits=True, callback=cb, **kw)
         args.seed = int(rng.sample_int(INT_MAX, 1)[0])
         s = make_sampler(args, rng.state)
         r = {}
         try:
+            names_box[:] = [s.stan_par_names()]
             if warmup > 0:
                 r["warmup"] = s.run(warmup, True, 0)
             s.disengage_adaptation()
@@ -359,7 +386,9 @@ def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=N
     def pack(phase):
         return dict(stan=_stack(results, phase, "stan"), bart_train=_stack(results, phase, "bart", "train"),
                     bart_test=_stack(results, phase, "bart", "test") if x_bart_test is not None else None,
-                    bart_varcount=_stack(results, phase, "bart", "varcount"))
+                    bart_varcount=_stack(results, phase, "bart", "varcount"),
+                    callback=(np.stack([np.stack(r[phase]["callback"], axis=1) for r in results], axis=2)
+                              if callback is not None else None))
     smp = pack("sample")
     n = len(y)
     Xa = np.zeros((n, 0)) if X is None else np.asarray(X, dtype=np.float64).reshape(n, -1)
@@ -374,4 +403,4 @@ def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=N
         X=Xa, X_means=np.asarray(args.extras["xbar"]), X_test=None if X_test is None else np.asarray(X_test, dtype=np.float64),
         terms=terms, terms_test=terms_test, offset=None if offset is None else np.asarray(offset, dtype=np.float64),
         offset_test=None if offset_test is None else np.asarray(offset_test, dtype=np.float64), offset_type=offset_type,
-        range_bart=np.stack([r["range.bart"] for r in results], axis=1), samplers=samplers)
+        range_bart=np.stack([r["range.bart"] for r in results], axis=1), samplers=samplers, callback=smp["callback"])

@@ -149,3 +149,37 @@ def test_predict_needs_kept_trees(emul_lib):
 def test_generics_on_hip(hip_lib, binary):
     fit, data = _fit(hip_lib, "s4b_", binary=binary)
     _check_surface(fit, data)
+
+
+def test_callback_and_treatment(emul_lib):
+    """reference tests/testthat/test-11-callback.R (the callback sees each draw: its pieces equal the extracted test
+    components) and test-10-treatment.R (treatment = ... builds the counterfactual test sample)."""
+    d, xb, X, groups, rows, groups_t = _data()
+    Xm = X.mean(axis=0)
+    lev1, lev2 = np.asarray(d["g1"]), np.asarray(d["g2"])
+
+    def cb(yhat_train, yhat_test, stan_pars, names):
+        beta = np.array([stan_pars[names.index(f"beta.{k + 1}")] for k in range(2)])
+        b = np.array([v for v, nm in zip(stan_pars, names) if nm.startswith("b.")])
+        fix = (X_cf - Xm) @ beta
+        # Z column order: g.2 (8 levels, intercept) then g.1 (5 levels, intercept + slope)
+        ran = b[lev2 - 1] + b[8 + (lev1 - 1) * 2] + b[8 + (lev1 - 1) * 2 + 1] * X_cf[:, 0]
+        return np.concatenate([yhat_test, fix, ran])
+
+    X_cf = X.copy()
+    X_cf[:, 1] = 1.0 - X[:, 1]
+    fit = stan4bart(d["y"], xb, X=X, groups=groups, treatment=("X", 1), callback=cb, chains=2, seed=5, iter=13, warmup=7,
+                    bart_args={"n.trees": 7}, make_sampler=lambda a, st: Sampler(emul_lib, "emu_", a, st))
+    n = len(d["y"])
+    cbk = fit.extract("callback", combine_chains=False)
+    assert cbk.shape == (3 * n, 6, 2)
+    np.testing.assert_allclose(cbk[:n], fit.extract("indiv.bart", sample="test", combine_chains=False), rtol=1e-12)
+    np.testing.assert_allclose(cbk[n:2 * n], fit.extract("indiv.fixef", sample="test", combine_chains=False), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(cbk[2 * n:], fit.extract("indiv.ranef", sample="test", combine_chains=False), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(cbk[:n] + cbk[n:2 * n] + cbk[2 * n:], fit.extract("ev", sample="test", combine_chains=False), rtol=1e-9)
+    # treatment effect samples: observed minus counterfactual differ exactly by the flipped column's coefficient
+    diff = fit.extract("ev", combine_chains=False) - fit.extract("ev", sample="test", combine_chains=False)
+    beta_z = fit.extract("fixef", combine_chains=False)[1]
+    np.testing.assert_allclose(diff, (X[:, 1] - X_cf[:, 1])[:, None, None] * beta_z[None], rtol=1e-8, atol=1e-8)
+    assert fit.fitted(sample="test").shape == (n,)
+    assert fit.extract("callback", include_warmup=True, combine_chains=False).shape == (3 * n, 13, 2)
