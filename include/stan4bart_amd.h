@@ -174,6 +174,12 @@ int S4B_FN(get_stan_par_names)(s4b_sampler* s, char* buf, size_t cap);
 int S4B_FN(get_trees)(s4b_sampler* s, int64_t cap, int32_t* tree, int32_t* n_obs, int32_t* var,
                       int32_t* split, double* value, int64_t* num_nodes);
 
+/* stan4bart_getTrees(current = FALSE) — src/init.cpp:514-671 over the draws kept while sampling (keep_trees; also on a
+ * stored sampler): sample < 0 selects every kept draw, otherwise that draw (0-based).  Same layout as get_trees plus
+ * the draw index of every node. */
+int S4B_FN(get_kept_trees)(s4b_sampler* s, int64_t sample, int64_t cap, int32_t* sample_index, int32_t* tree, int32_t* n_obs,
+                           int32_t* var, int32_t* split, double* value, int64_t* num_nodes);
+
 /* stan4bart_exportBARTState — src/init.cpp:409-416 (+ R/stan4bart_fit.R:572-580): the trees kept while sampling (keep_trees),
  * the cut points and the response scales as one relocatable byte string, so that a chain fitted in another process can be
  * predicted from.  Call with buf = NULL (or cap too small) to learn the size. */

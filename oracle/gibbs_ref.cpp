@@ -352,6 +352,39 @@ int orc_predict_bart(s4b_sampler* s, const double* x_test, int64_t n_test, doubl
   return 0;
 }
 
+int orc_get_kept_trees(s4b_sampler* s, int64_t sample, int64_t cap, int32_t* smp, int32_t* tree, int32_t* n_obs, int32_t* var, int32_t* split, double* value,
+                       int64_t* num_nodes) {
+  const int64_t S = (int64_t)s->kept.size();
+  if (sample >= S) { g_err = "sample index out of range"; return 1; }
+  const int T = s->stored ? s->storedT : s->bart->cfg.numTrees;
+  const std::vector<std::vector<double>>& cuts = s->stored ? s->storedCuts : s->bart->cuts;
+  int64_t cnt = 0;
+  for (int64_t k = sample < 0 ? 0 : sample; k < (sample < 0 ? S : sample + 1); ++k) {
+    const KeptSample& ks = s->kept[(size_t)k];
+    for (int t = 0; t < T; ++t) {
+      // the serialisation is already preorder: (var, split) for internal nodes, (-1, count) for leaves; counts of the
+      // internal nodes are the sums over their subtrees
+      size_t start = ks.treeStart[(size_t)t], leaf = ks.leafStart[(size_t)t];
+      size_t end = start; { int open = 1; while (open > 0) { if (ks.st[2 * end] >= 0) ++open; else --open; ++end; } }
+      std::vector<int32_t> nsub(end - start, 0);
+      for (size_t i = end; i-- > start;) {
+        if (ks.st[2 * i] < 0) nsub[i - start] = ks.st[2 * i + 1];
+        else { size_t l = i + 1; int open = 1; size_t r = l; while (open > 0) { if (ks.st[2 * r] >= 0) ++open; else --open; ++r; } nsub[i - start] = nsub[l - start] + nsub[r - start]; }
+      }
+      for (size_t i = start; i < end; ++i) {
+        if (cnt < cap && tree) {
+          smp[cnt] = (int32_t)k; tree[cnt] = t; n_obs[cnt] = nsub[i - start];
+          if (ks.st[2 * i] >= 0) { var[cnt] = ks.st[2 * i]; split[cnt] = ks.st[2 * i + 1]; value[cnt] = cuts[(size_t)ks.st[2 * i]][(size_t)ks.st[2 * i + 1]]; }
+          else { var[cnt] = -1; split[cnt] = -1; value[cnt] = ks.mu[leaf++]; }
+        } else if (ks.st[2 * i] < 0) ++leaf;
+        ++cnt;
+      }
+    }
+  }
+  *num_nodes = cnt;
+  return 0;
+}
+
 // exportBARTState / createStoredBARTSampler (reference src/init.cpp:409-446): the oracle's own byte layout
 int orc_export_bart_state(s4b_sampler* s, void* buf, int64_t cap, int64_t* size) {
   try {

@@ -254,7 +254,7 @@ class Sampler:
         for name in ("create", "run", "disengage_adaptation", "print_initial_summary", "get_parametric_mean",
                      "get_bart_data_range", "get_r_rng_state", "set_r_rng_state", "get_dims", "get_stan_par_names",
                      "get_trees", "set_trace", "get_trace", "get_leaf_assignment", "get_counters", "profile_sweep", "predict_bart",
-                     "export_bart_state", "create_stored_bart_sampler", "profile_leapfrog"):
+                     "export_bart_state", "create_stored_bart_sampler", "profile_leapfrog", "get_kept_trees"):
             getattr(self._lib, self._pfx + name).restype = C.c_int
         getattr(self._lib, self._pfx + "last_error").restype = C.c_char_p
         getattr(self._lib, self._pfx + "free").restype = None
@@ -336,6 +336,17 @@ class Sampler:
         self._check(self._f("get_trees")(self._h, m, _ip(tree), _ip(nobs), _ip(var), _ip(split), _dp(value), C.byref(nn)))
         return dict(tree=tree, n=nobs, var=var, split=split, value=value)
 
+    def get_kept_trees(self, sample: int = -1) -> dict:
+        """Flattened trees of the kept draws (``stan4bart_getTrees(current = FALSE)``; ``sample`` 0-based, -1 = all)."""
+        nn = C.c_int64()
+        self._check(self._f("get_kept_trees")(self._h, C.c_int64(sample), 0, None, None, None, None, None, None, C.byref(nn)))
+        m = nn.value
+        smp, tree, nobs, var, split = (np.zeros(m, dtype=np.int32) for _ in range(5))
+        value = np.zeros(m)
+        self._check(self._f("get_kept_trees")(self._h, C.c_int64(sample), m, _ip(smp), _ip(tree), _ip(nobs), _ip(var), _ip(split), _dp(value),
+                                              C.byref(nn)))
+        return dict(sample=smp, tree=tree, n=nobs, var=var, split=split, value=value)
+
     def set_trace(self, enable: bool):
         self._check(self._f("set_trace")(self._h, int(enable)))
 
@@ -413,10 +424,11 @@ class StoredSampler:
     _check = Sampler._check
     predict_bart = Sampler.predict_bart
     export_bart_state = Sampler.export_bart_state
+    get_kept_trees = Sampler.get_kept_trees
     free = Sampler.free
 
     def get_trees(self):
-        raise ValueError("a stored BART sampler only predicts")
+        return self.get_kept_trees()
 
     def __del__(self):
         try:

@@ -30,7 +30,7 @@ namespace s4b {
 enum { OFFSET_DEFAULT = 0, OFFSET_FIXEF, OFFSET_RANEF, OFFSET_BART, OFFSET_PARAMETRIC };
 
 // a node of a kept tree (predict): children are slot ids relative to the tree's first record
-struct PackedNode { int16_t var; uint16_t cut; int16_t left, right; double mu; };
+struct PackedNode { int16_t var; uint16_t cut; int16_t left, right; double mu; int32_t n; int32_t pad; };   // n: observations in the node
 
 // everything the device layer needs at creation (host pointers, valid during init() only)
 struct DevInit {
@@ -321,6 +321,30 @@ class SamplerCore {
     }
     return cnt;
   }
+  // stan4bart_getTrees(current = FALSE) over the kept draws (reference src/init.cpp:514-671; extract(fit, "trees", sampleNums = )):
+  // sample < 0: every kept draw, else that one (0-based); same flattened layout as get_trees plus the draw index
+  int64_t get_kept_trees(int64_t sample, int64_t cap, int32_t* smp, int32_t* tree, int32_t* n_obs, int32_t* var, int32_t* split, double* value) const {
+    const int64_t S = (int64_t)keptScale_.size() / 2;
+    if (sample >= S) throw std::invalid_argument("sample index out of range");
+    int64_t cnt = 0;
+    std::vector<int> stack;
+    for (int64_t k = sample < 0 ? 0 : sample; k < (sample < 0 ? S : sample + 1); ++k) for (int t = 0; t < T_; ++t) {
+      const PackedNode* base = keptNodes_.data() + keptTreeStart_[(size_t)(k * T_ + t)];
+      stack.assign(1, 0);
+      while (!stack.empty()) {   // preorder
+        const int nd = stack.back(); stack.pop_back();
+        const PackedNode& p = base[nd];
+        if (cnt < cap && tree) {
+          smp[cnt] = (int32_t)k; tree[cnt] = t; n_obs[cnt] = p.n;
+          if (p.var >= 0) { var[cnt] = p.var; split[cnt] = p.cut; value[cnt] = cuts_[(size_t)p.var][(size_t)p.cut]; }
+          else { var[cnt] = -1; split[cnt] = -1; value[cnt] = p.mu; }
+        }
+        ++cnt;
+        if (p.var >= 0) { stack.push_back(p.right); stack.push_back(p.left); }
+      }
+    }
+    return cnt;
+  }
   // stan4bart_predictBART over the trees kept while sampling (reference src/init.cpp:354-403)
   int64_t predict(const double* xTest, int64_t nT, double* out) {
     const int64_t S = (int64_t)keptScale_.size() / 2;
@@ -387,7 +411,14 @@ class SamplerCore {
       const size_t o = (size_t)t * nc_;
       for (int i = 0; i < h.hwm[(size_t)t]; ++i) {
         PackedNode pn; pn.var = h.var[o + i]; pn.cut = h.cut[o + i]; pn.left = h.left[o + i]; pn.right = h.right[o + i]; pn.mu = h.mu[o + i];
+        pn.n = pn.var == NODE_LEAF ? h.cnt[o + i] : 0; pn.pad = 0;
         keptNodes_.push_back(pn);
+      }
+      {   // observation counts of the internal nodes: children before parents
+        PackedNode* base = keptNodes_.data() + keptTreeStart_.back();
+        TreeView tv = h.view(t, nc_);
+        int nd, k; Walker<TreeView> w(tv, 0);
+        while (w.next(nd, k)) if (k == 2) base[nd].n = base[base[nd].left].n + base[base[nd].right].n;
       }
     }
     ScaleState sc; dev_.get_scale(sc);

@@ -161,9 +161,22 @@ class Stan4bartFit:
         if type not in EXTRACT_TYPES:
             raise ValueError(f"'type' must be one of {EXTRACT_TYPES}")
         if type == "trees":
+            # reference R/generics.R:186-193: the kept draws' trees (bart_args keepTrees), optionally one draw / some trees;
+            # columns chain, sample, tree, n, var (-1 = leaf), value (cut point | leaf mean on the BART scale)
             if not self.samplers:
                 raise ValueError("extracting trees requires stan4bart to be called with `bart_args = {'keepTrees': True}`")
-            return [s.get_trees() for s in self.samplers]
+            sample_nums, tree_nums, chain_nums = kw.get("sampleNums"), kw.get("treeNums"), kw.get("chainNums")
+            cols = {k: [] for k in ("chain", "sample", "tree", "n", "var", "split", "value")}
+            for c, smp in enumerate(self.samplers):
+                if chain_nums is not None and c not in np.atleast_1d(chain_nums):
+                    continue
+                parts = ([smp.get_kept_trees(-1)] if sample_nums is None else [smp.get_kept_trees(int(k)) for k in np.atleast_1d(sample_nums)])
+                for tr in parts:
+                    keep = np.ones(len(tr["tree"]), dtype=bool) if tree_nums is None else np.isin(tr["tree"], np.atleast_1d(tree_nums))
+                    cols["chain"].append(np.full(int(keep.sum()), c, dtype=np.int32))
+                    for k in ("sample", "tree", "n", "var", "split", "value"):
+                        cols[k].append(tr[k][keep])
+            return {k: np.concatenate(v) if v else np.zeros(0) for k, v in cols.items()}
         if sample not in ("train", "test"):
             raise ValueError("'sample' must be 'train' or 'test'")
         if isinstance(include_warmup, str):

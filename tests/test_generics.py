@@ -76,11 +76,57 @@ def _check_surface(fit, data):
     np.testing.assert_allclose(r0, g2_only, rtol=1e-12)
     r1 = fit.predict(x_bart=xb[:3], X=X[:3], groups=g_new, type="indiv.ranef", sample_new_levels=True, seed=3, combine_chains=False)
     assert np.std(r1 - r0) > 0
-    trees = fit.extract("trees")
-    assert len(trees) == C and set(trees[0]) == {"tree", "n", "var", "split", "value"}
+    _check_trees(fit, xb, rows, n)
     with pytest.raises(ValueError):
         fit.extract("nonsense")
     fit.close()
+
+
+def _check_trees(fit, xb, rows, n):
+    """reference tests/testthat/test-07-extractedTrees.R (all trees == the draws extracted one by one) plus: walking the
+    extracted trees reproduces predict's BART component."""
+    S, C = fit.bart_train.shape[1:]
+    T = 9
+    allt = fit.extract("trees")
+    assert set(allt) == {"chain", "sample", "tree", "n", "var", "split", "value"}
+    combos = set(zip(allt["chain"].tolist(), allt["sample"].tolist(), allt["tree"].tolist()))
+    assert combos == {(c, k, t) for c in range(C) for k in range(S) for t in range(T)}
+    one_by_one = [fit.extract("trees", sampleNums=k, chainNums=c) for c in range(C) for k in range(S)]
+    for key in allt:
+        np.testing.assert_array_equal(allt[key], np.concatenate([o[key] for o in one_by_one]))
+    sub = fit.extract("trees", treeNums=[2, 5])
+    assert set(np.unique(sub["tree"])) == {2, 5}
+    # root of every tree holds all observations; leaves of a tree partition them
+    first = np.r_[True, (np.diff(allt["tree"]) != 0) | (np.diff(allt["sample"]) != 0) | (np.diff(allt["chain"]) != 0)]
+    assert np.all(allt["n"][first] == n)
+    # prediction by walking the flattened trees (preorder: left subtree follows its parent)
+    x = xb[rows]
+    pred = np.zeros((len(rows), S, C))
+    pos = 0
+    var, val, ns = allt["var"], allt["value"], len(allt["var"])
+
+    def walk(i, xi):
+        while var[i] >= 0:
+            if xi[var[i]] <= val[i]:
+                i += 1
+            else:   # skip the left subtree
+                j, open_ = i + 1, 1
+                while open_ > 0:
+                    open_ += 1 if var[j] >= 0 else -1
+                    j += 1
+                i = j
+        return val[i], i
+    starts = np.flatnonzero(first)
+    for s_i, st in enumerate(starts):
+        c, k = allt["chain"][st], allt["sample"][st]
+        for r in range(len(rows)):
+            pred[r, k, c] += walk(st, x[r])[0]
+    bart = fit.predict(x_bart=x, type="indiv.bart", combine_chains=False)
+    if fit.family == "gaussian":
+        lo, hi = fit.range_bart[0], fit.range_bart[1]
+        # the range of the last draw is only exact for that draw (the scale is updated during warmup only, so it is constant here)
+        pred = (pred + 0.5) * (hi - lo)[None, None, :] + lo[None, None, :]
+    np.testing.assert_allclose(pred, bart, rtol=1e-9, atol=1e-9)
 
 
 def test_combine_chains():
@@ -109,8 +155,7 @@ def _check_stored(fit, data, lib, prefix):
                           np.asarray(g.slopes)[:23], g.name) for g in groups], type=t, combine_chains=False)
         np.testing.assert_array_equal(got, ref)
     assert fit.export_bart_states() == states                           # a stored sampler re-exports the same bytes
-    with pytest.raises((RuntimeError, ValueError), match="stored|only predicts"):
-        fit.extract("trees")
+    assert len(fit.extract("trees")["tree"]) > 0                        # kept trees travel with the state
     from stan4bart_amd.abi import StoredSampler
     with pytest.raises(RuntimeError, match="exported|truncated"):
         StoredSampler(lib, prefix, states[0][: len(states[0]) // 2])
@@ -183,3 +228,24 @@ def test_callback_and_treatment(emul_lib):
     np.testing.assert_allclose(diff, (X[:, 1] - X_cf[:, 1])[:, None, None] * beta_z[None], rtol=1e-8, atol=1e-8)
     assert fit.fitted(sample="test").shape == (n,)
     assert fit.extract("callback", include_warmup=True, combine_chains=False).shape == (3 * n, 13, 2)
+
+
+def test_kept_trees_match_oracle(oracle_lib, emul_lib):
+    a, _ = _fit(oracle_lib, "orc_", chains=1)
+    b, _ = _fit(emul_lib, "emu_", chains=1)
+    ta, tb = a.extract("trees"), b.extract("trees")
+    for k in ("chain", "sample", "tree", "n", "var", "split"):
+        np.testing.assert_array_equal(ta[k], tb[k])
+    np.testing.assert_allclose(ta["value"], tb["value"], rtol=1e-6, atol=1e-9)
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_kept_trees_match_oracle_on_hip(oracle_lib, hip_lib):
+    a, _ = _fit(oracle_lib, "orc_", chains=1)
+    b, _ = _fit(hip_lib, "s4b_", chains=1)
+    ta, tb = a.extract("trees"), b.extract("trees")
+    for k in ("chain", "sample", "tree", "n", "var", "split"):
+        np.testing.assert_array_equal(ta[k], tb[k])
+    np.testing.assert_allclose(ta["value"], tb["value"], rtol=1e-6, atol=1e-9)
+    a.close(); b.close()
