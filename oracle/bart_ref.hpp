@@ -83,6 +83,9 @@ class BartFit {
   RRng* rng = nullptr;
   std::vector<StepTrace> trace;
   bool keepTrace = false;
+  // observation weights (dbarts data@weights): a leaf's effective size is the sum of its weights, its average the
+  // weighted mean; emptiness and the reported node sizes stay counts
+  std::vector<double> weights;
 
   BartFit(const BartConfig& c, size_t n_, size_t p_, const double* x, const double* y_, const int* nCuts,
           size_t nTest_, const double* xTest, RRng* rng_)
@@ -297,9 +300,15 @@ class BartFit {
 
   void computeAverage(Node* nd) const {
     double s = 0.0;
-    for (size_t i : nd->obs) s += treeY[i];
-    nd->numEff = (double)nd->obs.size();
-    nd->average = nd->obs.empty() ? 0.0 : s / (double)nd->obs.size();
+    if (weights.empty()) {
+      for (size_t i : nd->obs) s += treeY[i];
+      nd->numEff = (double)nd->obs.size();
+    } else {
+      double w = 0.0;
+      for (size_t i : nd->obs) { s += weights[i] * treeY[i]; w += weights[i]; }
+      nd->numEff = w;
+    }
+    nd->average = nd->obs.empty() ? 0.0 : s / nd->numEff;
   }
   // push the observations of an internal node down to its descendants; recompute leaf averages
   void distribute(Node* nd) const {
@@ -339,7 +348,7 @@ class BartFit {
     if (m == 0) return 0.0;
     double ybar = b->average;
     double ss = 0.0;
-    for (size_t i : b->obs) { double d = treeY[i] - ybar; ss += d * d; }
+    for (size_t i : b->obs) { double d = treeY[i] - ybar; ss += (weights.empty() ? 1.0 : weights[i]) * d * d; }
     double var_y = m > 1 ? ss / (double)(m - 1) : 0.0;
     double resVar = sigma * sigma;
     double prec = precision();

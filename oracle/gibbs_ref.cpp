@@ -124,6 +124,10 @@ int orc_create(const s4b_bart_control* bc, const s4b_bart_data* bd, const s4b_st
     cfg.birthOrDeathProb = bc->birth_or_death_prob; cfg.swapProb = bc->swap_prob; cfg.changeProb = bc->change_prob; cfg.birthProb = bc->birth_prob;
     std::vector<int> ncuts(bd->n_cuts, bd->n_cuts + bd->p);
     s.bart.reset(new BartFit(cfg, s.n, (size_t)bd->p, bd->x, sd->y, ncuts.data(), (size_t)bd->n_test, bd->x_test, &s.rrng));
+    if (sd->has_weights) {
+      if (s.binary) throw std::invalid_argument("observation weights are not available for binary responses");
+      s.bart->weights.assign(sd->weights, sd->weights + s.n);
+    }
 
     s.bartOffset.assign(s.n, 0.0); s.stanOffset.assign(s.n, 0.0);
     if (s.binary) s.bartLatents.assign(s.n, 0.0);

@@ -23,7 +23,7 @@ struct StepScratch {
   int16_t *binA, *binB, *list; uint8_t* insub;
   double* muOld; Proposal* prop; int32_t* accepted;
   int16_t *pna, *pdep;                // node memo of the proposed tree (pointer path)
-  double* work;                       // [6][2 nc] decide() work arrays (pointer path)
+  double* work;                       // [7][2 nc] decide() work arrays (pointer path)
   int16_t* slab;                      // device: the nine int16 tables above are rows of one [SF_COUNT][nc] slab (one base address)
 };
 // row order of the slabs (the individual pointers are views into them)
@@ -62,6 +62,8 @@ struct BartArrays {
   StepScratch sc[2];
   double* partCnt; double* partSum;   // [binCap][grid] per-workgroup partials
   double* binCnt; double* binSum;     // [binCap]
+  const double* wts;                  // [n] observation weights or null (dbarts data@weights, Stan has_weights)
+  double* partWt; double* binWt;      // weight totals per bin, only with weights
   MTState* rng; ScaleState* scale; const int32_t* numCuts;
   StepRecord* trace; int32_t* traceCount; int32_t* errFlag;
   ModelView model;             // numCuts inside points to device memory
@@ -106,15 +108,16 @@ S4B_HD inline void control_step(const BartArrays& a, int t, int proposeNext) {
   TreeView cur = tree_view(a, t);
   StepTables tb = step_tables(a, t);
   const StepScratch& c = a.sc[t & 1];
-  PtrArr<double> mu(a.mu + (size_t)t * a.nc), muOld(c.muOld), binCnt(a.binCnt), binSum(a.binSum);
+  PtrArr<double> mu(a.mu + (size_t)t * a.nc), muOld(c.muOld), binCnt(a.binCnt), binSum(a.binSum), binWt(a.wts ? a.binWt : a.binCnt);
   PtrArr<int32_t> cnt(a.cnt + (size_t)t * a.nc);
   DecideWork<PtrArr<double>> wk;
   const size_t ws = (size_t)2 * a.nc;
   wk.ll = PtrArr<double>(c.work); wk.lc = PtrArr<double>(c.work + ws); wk.ls = PtrArr<double>(c.work + 2 * ws);
   wk.u1 = PtrArr<double>(c.work + 3 * ws); wk.u2 = PtrArr<double>(c.work + 4 * ws); wk.val = PtrArr<double>(c.work + 5 * ws);
+  wk.lw = PtrArr<double>(c.work + 6 * ws);
   StepRecord rec;
   TreeCache ca = tree_cache(a, t);
-  a.hwm[t] = decide(cur, mu, cnt, muOld, a.hwm[t], a.model, a.scale->sigma, a.rng, c.prop, tb, binCnt, binSum, wk, c.accepted,
+  a.hwm[t] = decide(cur, mu, cnt, muOld, a.hwm[t], a.model, a.scale->sigma, a.rng, c.prop, tb, binCnt, binSum, binWt, wk, c.accepted,
                     a.traceOn ? &rec : nullptr, ca);
   a.cnl[t] = ca.nl; a.cni[t] = ca.ni; a.cg[t] = ca.g; a.cgn[t] = ca.gn; a.clogpi[t] = ca.logPi;   // (lists are written in place)
   if (a.traceOn) push_trace(a, rec);

@@ -40,6 +40,7 @@ struct DevInit {
   const int32_t* numCuts = nullptr;
   const double* y = nullptr;
   const double* userOffset = nullptr;
+  const double* weights = nullptr;     // [n] or null
   ModelView model;
   int32_t K = 0, q = 0, binary = 0;
   const double* X = nullptr;           // n x K column-major
@@ -96,7 +97,12 @@ class SamplerCore {
     if (!(cc->sigma_init > 0)) throw std::invalid_argument("sigma_init must be > 0");
     if ((cc->is_binary != 0) != (sd->is_binary != 0)) throw std::invalid_argument("common_control.is_binary and stan_data.is_binary disagree");
     binary_ = cc->is_binary != 0;
-    if (sd->has_weights) throw std::invalid_argument("weights are not supported by the device path yet");
+    if (sd->has_weights) {
+      if (!sd->weights) throw std::invalid_argument("has_weights = 1 but weights is NULL");
+      if (cc->is_binary) throw std::invalid_argument("observation weights are not available for binary responses");
+      for (int64_t i = 0; i < sd->N; ++i) if (!(sd->weights[i] > 0.0)) throw std::invalid_argument("weights must be positive");
+      weights_.assign(sd->weights, sd->weights + sd->N);
+    }
     if (sd->has_intercept) throw std::invalid_argument("has_intercept = 1 is not supported (BART supplies the intercept)");
     if (sd->prior_dist < 0 || sd->prior_dist > 7) throw std::invalid_argument("prior_dist must be in 0..7");
     if ((sd->prior_dist == 3 || sd->prior_dist == 4) && cc->is_binary) throw std::invalid_argument("hs priors scale with the residual sd: not available for binary responses");
@@ -145,7 +151,7 @@ class SamplerCore {
     DevInit di;
     di.n = (int64_t)n_; di.nTest = (int64_t)nTest_; di.P = P_; di.T = T_; di.nc = nc_; di.device = cc->device;
     di.xbin = xbin.data(); di.xbinTest = nTest_ ? xbinTest.data() : nullptr; di.numCuts = numCuts_.data();
-    di.y = sd->y; di.userOffset = hasUserOffset_ ? userOffset_.data() : nullptr;
+    di.y = sd->y; di.userOffset = hasUserOffset_ ? userOffset_.data() : nullptr; di.weights = weights_.empty() ? nullptr : weights_.data();
     di.model.P = P_; di.model.Pvalid = 0;
     for (int j = 0; j < P_; ++j) if (numCuts_[(size_t)j] > 0) ++di.model.Pvalid;
     if (di.model.Pvalid == 0) throw std::invalid_argument("no predictor has a cut point");
@@ -396,6 +402,7 @@ class SamplerCore {
     uint64_t u64() { uint64_t v; get(&v, 8); return v; }
   };
   bool stored_ = false; int64_t nnz_ = 0;
+  std::vector<double> weights_;
   void live() const { if (stored_) throw std::invalid_argument("this call needs a live sampler: a stored BART sampler only predicts"); }
   struct HostTrees {
     std::vector<int16_t> var, left, right, parent, na, dep; std::vector<uint16_t> cut; std::vector<double> mu; std::vector<int32_t> cnt, hwm;
@@ -509,7 +516,8 @@ class SamplerCore {
       idx.clear(); val.clear();
       for (int k = 0; k < K_; ++k) { idx.push_back(k); val.push_back(sd->X[(size_t)k * sd->N + i]); }
       if (q_) for (int e = sd->u[i]; e < sd->u[i + 1]; ++e) { idx.push_back(K_ + sd->v[e]); val.push_back(sd->w[e]); }
-      for (size_t a = 0; a < idx.size(); ++a) for (size_t b = 0; b < idx.size(); ++b) dense[(size_t)idx[a] * M + idx[b]] += val[a] * val[b];
+      const double wi = weights_.empty() ? 1.0 : weights_[(size_t)i];   // weighted likelihood: G = [X Z]' W [X Z]
+      for (size_t a = 0; a < idx.size(); ++a) for (size_t b = 0; b < idx.size(); ++b) dense[(size_t)idx[a] * M + idx[b]] += wi * val[a] * val[b];
     }
     gramPtr_.assign((size_t)M + 1, 0); gramCol_.clear(); gram_.clear();
     for (int a = 0; a < M; ++a) {
@@ -517,7 +525,7 @@ class SamplerCore {
       gramPtr_[(size_t)a + 1] = (int)gramCol_.size();
     }
   }
-  // ss = |e|^2, gX = X'e, gZ = Z'e with e = (y - offset) - X beta - Z b
+  // ss = e'We, gX = X'We, gZ = Z'We with e = (y - offset) - X beta - Z b (W = I without weights)
   double likelihood(const double* beta, const double* b, double* gX, double* gZ) {
     if (hmcMode_ != 0) return dev_.leapfrog_sums(beta, b, gX, gZ);
     const int M = K_ + q_;

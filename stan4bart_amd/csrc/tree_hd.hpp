@@ -618,19 +618,20 @@ template <class AF64> S4B_HD inline void copy_leaf_values(const AF64& mu, AF64& 
 
 // batched math (defaults: element by element; the wave policy overloads them lane-parallel)
 template <class ABIN, class AOUT>
-S4B_HD inline void bins_loglik(const ABIN& binCnt, const ABIN& binSum, int nb, double sigma2, double prec, AOUT& out) {
-  for (int b = 0; b < nb; ++b) { double c = binCnt.get(b); out.set(b, c == 0.0 ? 0.0 : leaf_loglik(c, binSum.get(b), sigma2, prec)); }
+S4B_HD inline void bins_loglik(const ABIN& binCnt, const ABIN& binSum, const ABIN& binWt, int nb, double sigma2, double prec, AOUT& out) {
+  for (int b = 0; b < nb; ++b) { double c = binCnt.get(b); out.set(b, c == 0.0 ? 0.0 : leaf_loglik(binWt.get(b), binSum.get(b), sigma2, prec)); }
 }
-// leaf i (DFS rank): value from its sufficient statistics and the two uniforms drawn for it
+// leaf i (DFS rank): value from its sufficient statistics (count lc, weighted sum ls, weight lw) and the two uniforms drawn for it
 template <class AF64>
-S4B_HD inline void leaves_draw(const AF64& lc, const AF64& ls, const AF64& u1, const AF64& u2, int nl, double sigma2, double prec, AF64& out) {
+S4B_HD inline void leaves_draw(const AF64& lc, const AF64& ls, const AF64& lw, const AF64& u1, const AF64& u2, int nl, double sigma2, double prec, AF64& out) {
   for (int i = 0; i < nl; ++i) {
     double c = lc.get(i);
     if (c == 0.0) { out.set(i, 0.0); continue; }
     const double BIG = 134217728.0;
     double z = r_qnorm(((double)(int)(BIG * u1.get(i)) + u2.get(i)) / BIG);
-    double postPrec = c / sigma2;
-    double mean = postPrec * (ls.get(i) / c) / (prec + postPrec);
+    double w = lw.get(i);
+    double postPrec = w / sigma2;
+    double mean = postPrec * (ls.get(i) / w) / (prec + postPrec);
     double sd = 1.0 / sqrt(prec + postPrec);
     out.set(i, mean + sd * z);
   }
@@ -639,15 +640,17 @@ S4B_HD inline void leaves_draw(const AF64& lc, const AF64& ls, const AF64& u1, c
 // Consumes the bins of the pending proposal: accept/reject, update the tree (cur, mu, cnt), draw the
 // leaf parameters.  muOld receives the pre-update leaf values by old node id (the apply kernel needs
 // them); tb.insub keeps the "re-route" flags for the apply kernel.  Returns the new hwm.
+// binWt: sum of the observation weights per bin (pass binCnt itself when there are no weights); counts decide emptiness
+// and the reported node sizes, weights the precision.
 // work arrays of decide(): nb (<= bin capacity) log-likelihoods, per-leaf stats / uniforms / values
 template <class AF64>
-struct DecideWork { AF64 ll, lc, ls, u1, u2, val; };
+struct DecideWork { AF64 ll, lc, ls, u1, u2, val, lw; };
 
 struct NoHook { S4B_HD void operator()() const {} };
 // `drawsDone` is called once the last random number of the step has been consumed (before the batched leaf arithmetic)
 template <class TR, class TBL, class AF64, class AI32, class ABIN, class CA, class MV, class RNG, class HOOK = NoHook>
 S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, const MV& m, double sigma, RNG* rng,
-                         const Proposal* pr, TBL& tb, const ABIN& binCnt, const ABIN& binSum, DecideWork<AF64>& wk,
+                         const Proposal* pr, TBL& tb, const ABIN& binCnt, const ABIN& binSum, const ABIN& binWt, DecideWork<AF64>& wk,
                          int32_t* accepted, StepRecord* rec, CA& ca, const HOOK& drawsDone = HOOK()) {
   TR& pt = tb.prop;
   sigma = S4B_UNI(sigma);
@@ -658,7 +661,7 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
   const int nbAll = S4B_UNI(pr->nbA) + S4B_UNI(pr->nbB);
   if (prStatus == 1) {
     const int nd = prNode;
-    bins_loglik(binCnt, binSum, nbAll, sigma2, m.leafPrec, wk.ll);
+    bins_loglik(binCnt, binSum, binWt, nbAll, sigma2, m.leafPrec, wk.ll);
     double oldLL = 0.0, newLL = 0.0; bool oldEmpty = false, newEmpty = false;
     if (prType == MOVE_BIRTH) {          // old branch = the leaf itself, new branch = its two children (left, right)
       int b0 = tb.binA.get(nd);
@@ -670,8 +673,8 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
       int bl = tb.binA.get(cur.left.get(nd)), br = tb.binA.get(cur.right.get(nd));
       if (binCnt.get(bl) == 0.0) oldEmpty = true; else oldLL += wk.ll.get(bl);
       if (binCnt.get(br) == 0.0) oldEmpty = true; else oldLL += wk.ll.get(br);
-      double c = binCnt.get(bl) + binCnt.get(br), s = binSum.get(bl) + binSum.get(br);
-      if (c == 0.0) newEmpty = true; else newLL = leaf_loglik(c, s, sigma2, m.leafPrec);
+      double c = binCnt.get(bl) + binCnt.get(br), s = binSum.get(bl) + binSum.get(br), wt = binWt.get(bl) + binWt.get(br);
+      if (c == 0.0) newEmpty = true; else newLL = leaf_loglik(wt, s, sigma2, m.leafPrec);
     } else {                             // swap / change: same leaves (DFS order) under nd before and after —
       const int nlAll = ca.nl;           // exactly the leaves of the tree that carry a B bin, in the cached DFS order
       for (int i = 0; i < nlAll; ++i) {
@@ -694,11 +697,11 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
   // draws are consumed in that order, the (expensive) quantile / posterior arithmetic is batched afterwards
   const bool deathAcc = acc && prType == MOVE_DEATH;
   const int nd = prNode;
-  double cDeath = 0.0, sDeath = 0.0;
+  double cDeath = 0.0, sDeath = 0.0, wDeath = 0.0;
   if (deathAcc) {
     int L = cur.left.get(nd), R = cur.right.get(nd);
     int bl = tb.binA.get(L), br = tb.binA.get(R);
-    cDeath = binCnt.get(bl) + binCnt.get(br); sDeath = binSum.get(bl) + binSum.get(br);
+    cDeath = binCnt.get(bl) + binCnt.get(br); sDeath = binSum.get(bl) + binSum.get(br); wDeath = binWt.get(bl) + binWt.get(br);
     tb.insub.set(L, 1); tb.insub.set(R, 1);
   }
   if (acc) {
@@ -737,18 +740,18 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
   const int nl = ca.nl;
   for (int i = 0; i < nl; ++i) {
     int n = ca.leaf.get(i);
-    double lc, ls;
-    if (deathAcc && n == nd) { lc = cDeath; ls = sDeath; }
+    double lc, ls, lw;
+    if (deathAcc && n == nd) { lc = cDeath; ls = sDeath; lw = wDeath; }
     else {
       int bB = tb.binB.get(n);
       int b = (acc && !deathAcc && bB >= 0) ? bB : (int)tb.binA.get(n);
-      lc = binCnt.get(b); ls = binSum.get(b);
+      lc = binCnt.get(b); ls = binSum.get(b); lw = binWt.get(b);
     }
-    wk.lc.set(i, lc); wk.ls.set(i, ls);
+    wk.lc.set(i, lc); wk.ls.set(i, ls); wk.lw.set(i, lw);
     if (lc != 0.0) { wk.u1.set(i, r_unif(rng)); wk.u2.set(i, r_unif(rng)); }
   }
   drawsDone();
-  leaves_draw(wk.lc, wk.ls, wk.u1, wk.u2, nl, sigma2, m.leafPrec, wk.val);
+  leaves_draw(wk.lc, wk.ls, wk.lw, wk.u1, wk.u2, nl, sigma2, m.leafPrec, wk.val);
   for (int i = 0; i < nl; ++i) { int n = ca.leaf.get(i); cnt.set(n, (int32_t)wk.lc.get(i)); mu.set(n, wk.val.get(i)); }
   if (rec) { rec->type = prType; rec->status = prStatus == 1 ? acc : -1; rec->var = pr->var; rec->split = pr->split; rec->numLeaves = nl; }
   *accepted = acc;

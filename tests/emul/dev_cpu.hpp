@@ -40,9 +40,10 @@ class DevCpu {
       sc_[s].pcut.assign((size_t)nc_, 0); sc_[s].binA.assign((size_t)nc_, 0); sc_[s].binB.assign((size_t)nc_, 0); sc_[s].list.assign((size_t)nc_, 0);
       sc_[s].insub.assign((size_t)nc_, 0); sc_[s].muOld.assign((size_t)nc_, 0.0);
       sc_[s].pna.assign((size_t)nc_, 0); sc_[s].pdep.assign((size_t)nc_, 0);
-      sc_[s].work.assign((size_t)12 * nc_, 0.0);
+      sc_[s].work.assign((size_t)14 * nc_, 0.0);
     }
-    binCnt_.assign((size_t)2 * nc_, 0.0); binSum_.assign((size_t)2 * nc_, 0.0);
+    binCnt_.assign((size_t)2 * nc_, 0.0); binSum_.assign((size_t)2 * nc_, 0.0); binWt_.assign((size_t)2 * nc_, 0.0);
+    if (d.weights) wts_.assign(d.weights, d.weights + n_);
     trace_.assign((size_t)d.traceCap, StepRecord{});
     // arrays view
     a_ = BartArrays{};
@@ -62,6 +63,7 @@ class DevCpu {
       c.pna = sc_[s].pna.data(); c.pdep = sc_[s].pdep.data(); c.work = sc_[s].work.data();
     }
     a_.partCnt = nullptr; a_.partSum = nullptr; a_.binCnt = binCnt_.data(); a_.binSum = binSum_.data();
+    a_.wts = wts_.empty() ? nullptr : wts_.data(); a_.partWt = nullptr; a_.binWt = binWt_.data();
     a_.rng = &rng_; a_.scale = &scale_; a_.numCuts = numCuts_.data();
     a_.trace = trace_.data(); a_.traceCount = &traceCount_; a_.errFlag = &err_;
     a_.model = d.model; a_.model.numCuts = numCuts_.data(); a_.traceOn = 0;
@@ -235,9 +237,10 @@ class DevCpu {
       double so = mode == 0 ? 0.0 : mode == 1 ? fit : mode == 2 ? user_[i] : fit + user_[i];
       double e = resp - so;
       e0_[i] = e;
-      ss += e * e;
-      for (int k = 0; k < K_; ++k) cX[k] += X_[(size_t)k * n_ + i] * e;
-      if (q_) for (int z = u_[i]; z < u_[i + 1]; ++z) cZ[v_[(size_t)z]] += w_[(size_t)z] * e;
+      const double we = wts_.empty() ? e : wts_[i] * e;
+      ss += we * e;
+      for (int k = 0; k < K_; ++k) cX[k] += X_[(size_t)k * n_ + i] * we;
+      if (q_) for (int z = u_[i]; z < u_[i + 1]; ++z) cZ[v_[(size_t)z]] += w_[(size_t)z] * we;
       if (wantTrain && trainOut) trainOut[i] = fit;
     }
     *s0 = ss;
@@ -250,9 +253,10 @@ class DevCpu {
       double e = e0_[i];
       for (int k = 0; k < K_; ++k) e -= X_[(size_t)k * n_ + i] * beta[k];
       if (q_) for (int z = u_[i]; z < u_[i + 1]; ++z) e -= w_[(size_t)z] * b[v_[(size_t)z]];
-      ss += e * e;
-      for (int k = 0; k < K_; ++k) gX[k] += X_[(size_t)k * n_ + i] * e;
-      if (q_) for (int z = u_[i]; z < u_[i + 1]; ++z) gZ[v_[(size_t)z]] += w_[(size_t)z] * e;
+      const double we = wts_.empty() ? e : wts_[i] * e;
+      ss += we * e;
+      for (int k = 0; k < K_; ++k) gX[k] += X_[(size_t)k * n_ + i] * we;
+      if (q_) for (int z = u_[i]; z < u_[i + 1]; ++z) gZ[v_[(size_t)z]] += w_[(size_t)z] * we;
     }
     return ss;
   }
@@ -262,19 +266,21 @@ class DevCpu {
     const StepScratch& c = a_.sc[t & 1];
     const Proposal& pr = *c.prop;
     int nb = pr.nbA + pr.nbB;
-    for (int k = 0; k < nb; ++k) { binCnt_[(size_t)k] = 0.0; binSum_[(size_t)k] = 0.0; }
+    for (int k = 0; k < nb; ++k) { binCnt_[(size_t)k] = 0.0; binSum_[(size_t)k] = 0.0; binWt_[(size_t)k] = 0.0; }
+    const bool wt = !wts_.empty();
     const double* mu = &mu_[(size_t)t * nc_];
     const uint16_t* leaf = &leaf_[(size_t)t * n_];
     for (size_t i = 0; i < n_; ++i) {
       int lf = leaf[i];
-      double r = R_[i] + mu[lf];
+      const double wi = wt ? wts_[i] : 1.0;
+      double r = (R_[i] + mu[lf]) * wi;
       int a = c.binA[lf];
-      binCnt_[(size_t)a] += 1.0; binSum_[(size_t)a] += r;
+      binCnt_[(size_t)a] += 1.0; binSum_[(size_t)a] += r; binWt_[(size_t)a] += wi;
       if (c.insub[lf]) {
         int nd = pr.node;
         while (c.pvar[nd] >= 0) nd = (xbin_[(size_t)c.pvar[nd] * n_ + i] <= c.pcut[nd]) ? c.pleft[nd] : c.pright[nd];
         int b = c.binB[nd];
-        binCnt_[(size_t)b] += 1.0; binSum_[(size_t)b] += r;
+        binCnt_[(size_t)b] += 1.0; binSum_[(size_t)b] += r; binWt_[(size_t)b] += wi;
       }
     }
   }
@@ -302,7 +308,7 @@ class DevCpu {
   size_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0;
   std::vector<uint16_t> xbin_, xbinTest_, leaf_, cut_;
   std::vector<int32_t> numCuts_, cnt_, hwm_, v_, u_;
-  std::vector<double> y_, user_, X_, w_, R_, off_, offNew_, e0_, mu_, binCnt_, binSum_, lat_; bool binary_ = false;
+  std::vector<double> y_, user_, X_, w_, R_, off_, offNew_, e0_, mu_, binCnt_, binSum_, binWt_, wts_, lat_; bool binary_ = false;
   std::vector<int16_t> var_, left_, right_, parent_, cna_, cdep_, cleaf_, cpre_, cpost_;
   std::vector<int32_t> cnl_, cni_, cg_, cgn_, cvalid_; std::vector<double> clogpi_;
   Scratch sc_[2];

@@ -95,7 +95,8 @@ def test_error_reporting(emul_lib):
         run_chain(emul_lib, "emu_", args)
     args, _ = friedman_case()
     args.weights = np.ones(100) * 2.0
-    with pytest.raises(RuntimeError, match="weights"):
+    args.weights[3] = 0.0
+    with pytest.raises(RuntimeError, match="weights must be positive"):
         run_chain(emul_lib, "emu_", args)
 
 
@@ -207,3 +208,20 @@ def test_predict_equals_extract(oracle_lib, emul_lib, family):
         res[key] = (ptrain, ptest)
     np.testing.assert_allclose(res["o"][0], res["e"][0], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(res["o"][1], res["e"][1], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(stan_args={"hmc_mode": 1}), dict(ranef=False, n=300, T=20, warmup=10, iter=25)], ids=str)
+def test_observation_weights_match_oracle(oracle_lib, emul_lib, kw):
+    """weights reach both blocks: dbarts' weighted leaf statistics and continuous.stan's weighted likelihood (:358-366)."""
+    kw_o = {k: v for k, v in kw.items() if k != "stan_args"}
+    n = kw.get("n", 100)
+    w = np.random.default_rng(5).uniform(0.3, 3.0, n)
+    a = run_chain(oracle_lib, "orc_", friedman_case(weights=w, **kw_o)[0])
+    b = run_chain(emul_lib, "emu_", friedman_case(weights=w, **kw)[0])
+    assert_chain_parity(a, b)
+    c = run_chain(emul_lib, "emu_", friedman_case(**kw)[0])
+    assert not np.array_equal(b["sample"]["bart"]["train"], c["sample"]["bart"]["train"])     # the weights matter
+    # constant weights c are the same model as sigma -> sigma / sqrt(c): unit weights reproduce the unweighted chain exactly
+    d = run_chain(emul_lib, "emu_", friedman_case(weights=np.ones(n), **kw)[0])
+    np.testing.assert_array_equal(d["trace"], c["trace"])
+    np.testing.assert_allclose(d["sample"]["bart"]["train"], c["sample"]["bart"]["train"], rtol=1e-9, atol=1e-9)
