@@ -112,10 +112,10 @@ static size_t apply_lds_bytes(int nc) { return (size_t)nc * 25 + 16; }
 struct TreeLds {
   NodeS* S; NodeP* SP;     // stats: records + proposed-tree routing
   NodeA* A; NodeP* AP; uint8_t* Ain;   // apply: records + new-tree routing + re-route flags
-  double* redS; int* redN;
+  double* redS; int* redN; double* redW;
 };
 __host__ __device__ static inline size_t tree_lds_bytes(int nc) {
-  return (size_t)nc * (16 + 8 + 16 + 8) + ((size_t)nc + 15) / 16 * 16 + 4 * 16 * 8 + 4 * 16 * 4;
+  return (size_t)nc * (16 + 8 + 16 + 8) + ((size_t)nc + 15) / 16 * 16 + 4 * 16 * 8 + 4 * 16 * 4 + 4 * 16 * 8;
 }
 __device__ __forceinline__ TreeLds carve_tree(unsigned char* base, int nc) {
   TreeLds L;
@@ -125,16 +125,18 @@ __device__ __forceinline__ TreeLds carve_tree(unsigned char* base, int nc) {
   L.AP = (NodeP*)base; base += (size_t)nc * 8;
   L.Ain = (uint8_t*)base; base += ((size_t)nc + 15) / 16 * 16;
   L.redS = (double*)base; base += 4 * 16 * 8;
+  L.redW = (double*)base; base += 4 * 16 * 8;
   L.redN = (int*)base;
   return L;
 }
 
-template <int NB, bool APPLY>
+template <int NB, bool APPLY, bool WEIGHTED>
 __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const TreeLds& L, int root, int prevRoot, int prevAcc, int base,
                                           int nbTotal) {
-  double accS[NB]; int accN[NB];
+  double accS[NB]; int accN[NB]; double accW[WEIGHTED ? NB : 1];
 #pragma unroll
-  for (int k = 0; k < NB; ++k) { accS[k] = 0.0; accN[k] = 0; }
+  for (int k = 0; k < NB; ++k) { accS[k] = 0.0; accN[k] = 0; if (WEIGHTED) accW[k] = 0.0; }
+  const double* __restrict__ W = a.wts;
   const int64_t nQuads = (a.n + 3) >> 2;
   const uint16_t* __restrict__ leafPlane = a.leaf + (size_t)t * a.npad;
   uint16_t* __restrict__ prevPlane = a.leaf + (size_t)(t > 0 ? t - 1 : 0) * a.npad;
@@ -142,22 +144,25 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
   int64_t qd = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   // software prefetch: the loads of the next quad are issued before the current one is processed
-  double2 r01, r23; us4_t lf4, pl4;
+  double2 r01, r23; us4_t lf4, pl4; double2 w01 = make_double2(1.0, 1.0), w23 = make_double2(1.0, 1.0);
   if (qd < nQuads) {
     const int64_t i0 = qd << 2;
     r01 = *reinterpret_cast<const double2*>(R + i0); r23 = *reinterpret_cast<const double2*>(R + i0 + 2);
+    if (WEIGHTED) { w01 = *reinterpret_cast<const double2*>(W + i0); w23 = *reinterpret_cast<const double2*>(W + i0 + 2); }
     lf4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(leafPlane + i0));
     if (APPLY) pl4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(prevPlane + i0));
   }
   for (; qd < nQuads; qd += stride) {
     const int64_t i0 = qd << 2;
     double rr[4] = {r01.x, r01.y, r23.x, r23.y};
+    const double ww[4] = {w01.x, w01.y, w23.x, w23.y};
     const unsigned lf[4] = {lf4.x, lf4.y, lf4.z, lf4.w};
     unsigned pl[4] = {pl4.x, pl4.y, pl4.z, pl4.w};
     const int64_t qn = qd + stride;
     if (qn < nQuads) {
       const int64_t j0 = qn << 2;
       r01 = *reinterpret_cast<const double2*>(R + j0); r23 = *reinterpret_cast<const double2*>(R + j0 + 2);
+      if (WEIGHTED) { w01 = *reinterpret_cast<const double2*>(W + j0); w23 = *reinterpret_cast<const double2*>(W + j0 + 2); }
       lf4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(leafPlane + j0));
       if (APPLY) pl4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(prevPlane + j0));
     }
@@ -192,7 +197,7 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
     for (int e = 0; e < 4; ++e) {
       const bool ok = e < valid;
       const NodeS ns = L.S[ok ? lf[e] : 0u];
-      const double r = rr[e] + ns.mu;
+      const double r = WEIGHTED ? (rr[e] + ns.mu) * ww[e] : rr[e] + ns.mu;
       const int ba = ok ? (int)ns.binA - base : -1;
       int bb = -1 - base;
       if (ok && ns.insub) {
@@ -210,6 +215,7 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
         const bool m = (ba == k) | (bb == k);
         accS[k] += m ? r : 0.0;
         accN[k] += m ? 1 : 0;
+        if (WEIGHTED) accW[k] += m ? ww[e] : 0.0;
       }
     }
   }
@@ -217,7 +223,9 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   wave_sum_bins<NB>(accS, lane);
   wave_sum_bins<NB>(accN, lane);
-  if ((lane & (64 / NB - 1)) == 0) { const int k = wave_bin_of_lane<NB>(lane); L.redS[wv * NBMAX + k] = accS[0]; L.redN[wv * NBMAX + k] = accN[0]; }
+  if (WEIGHTED) wave_sum_bins<WEIGHTED ? NB : 1>(accW, lane);
+  if ((lane & (64 / NB - 1)) == 0) { const int k = wave_bin_of_lane<NB>(lane); L.redS[wv * NBMAX + k] = accS[0]; L.redN[wv * NBMAX + k] = accN[0];
+                                     if (WEIGHTED) L.redW[wv * NBMAX + k] = accW[0]; }
   __syncthreads();
   if ((int)threadIdx.x < NB && base + (int)threadIdx.x < nbTotal) {
     const int k = threadIdx.x;
@@ -225,12 +233,14 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
     const int c = L.redN[k] + L.redN[NBMAX + k] + L.redN[2 * NBMAX + k] + L.redN[3 * NBMAX + k];
     a.partSum[(size_t)(base + k) * a.grid + blockIdx.x] = s;
     a.partCnt[(size_t)(base + k) * a.grid + blockIdx.x] = (double)c;
+    if (WEIGHTED) a.partWt[(size_t)(base + k) * a.grid + blockIdx.x] = ((L.redW[k] + L.redW[NBMAX + k]) + L.redW[2 * NBMAX + k]) + L.redW[3 * NBMAX + k];
   }
   __syncthreads();
 }
 
 // APPLY = false for the first tree of a sweep (nothing pending)
-template <bool APPLY>
+// WEIGHTED: observation weights (8 more bytes per observation; bins per pass capped at 8 to stay within the register budget)
+template <bool APPLY, bool WEIGHTED>
 __global__ __launch_bounds__(BLOCK) void k_tree(BartArrays a, int t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   S4B_TICK(tq0);
@@ -258,12 +268,14 @@ __global__ __launch_bounds__(BLOCK) void k_tree(BartArrays a, int t) {
   __syncthreads();
   S4B_TICK(tq1);
   const int nb = pr.nbA + pr.nbB;
-  if (nb <= 4) tree_pass<4, APPLY>(a, t, L, pr.node, prevRoot, prevAcc, 0, nb);
-  else if (nb <= 8) tree_pass<8, APPLY>(a, t, L, pr.node, prevRoot, prevAcc, 0, nb);
-  else {
-    tree_pass<NBMAX, APPLY>(a, t, L, pr.node, prevRoot, prevAcc, 0, nb);
+  if (nb <= 4) tree_pass<4, APPLY, WEIGHTED>(a, t, L, pr.node, prevRoot, prevAcc, 0, nb);
+  else if (nb <= 8 || WEIGHTED) {
+    tree_pass<8, APPLY, WEIGHTED>(a, t, L, pr.node, prevRoot, prevAcc, 0, nb);
+    for (int base = 8; base < nb; base += 8) tree_pass<8, false, WEIGHTED>(a, t, L, pr.node, prevRoot, prevAcc, base, nb);
+  } else {
+    tree_pass<NBMAX, APPLY, WEIGHTED>(a, t, L, pr.node, prevRoot, prevAcc, 0, nb);
     // further bin passes read the residual this thread has just written
-    for (int base = NBMAX; base < nb; base += NBMAX) tree_pass<NBMAX, false>(a, t, L, pr.node, prevRoot, prevAcc, base, nb);
+    for (int base = NBMAX; base < nb; base += NBMAX) tree_pass<NBMAX, false, WEIGHTED>(a, t, L, pr.node, prevRoot, prevAcc, base, nb);
   }
 #ifdef S4B_CONTROL_TIMING
   { S4B_TICK(tq2);
@@ -315,19 +327,20 @@ __device__ __forceinline__ void copy_leaf_values(const WaveArrD& mu, WaveArrD& m
   muOld.lo = in ? mu.lo : 0; muOld.hi = in ? mu.hi : 0;
 }
 // lane-parallel versions of the batched math of decide(): lane b / lane i owns bin b / leaf i
-__device__ __forceinline__ void bins_loglik(const WaveArrD& binCnt, const WaveArrD& binSum, int, double sigma2, double prec, WaveArrD& out) {
+__device__ __forceinline__ void bins_loglik(const WaveArrD& binCnt, const WaveArrD& binSum, const WaveArrD& binWt, int, double sigma2, double prec, WaveArrD& out) {
   const double c = binCnt.mine();
-  out.load(c == 0.0 ? 0.0 : leaf_loglik(c, binSum.mine(), sigma2, prec));
+  out.load(c == 0.0 ? 0.0 : leaf_loglik(binWt.mine(), binSum.mine(), sigma2, prec));
 }
-__device__ __forceinline__ void leaves_draw(const WaveArrD& lc, const WaveArrD& ls, const WaveArrD& u1, const WaveArrD& u2, int nl, double sigma2,
-                                            double prec, WaveArrD& out) {
+__device__ __forceinline__ void leaves_draw(const WaveArrD& lc, const WaveArrD& ls, const WaveArrD& lw, const WaveArrD& u1, const WaveArrD& u2, int nl,
+                                            double sigma2, double prec, WaveArrD& out) {
   const double c = lc.mine();
   double v = 0.0;
   if ((int)(threadIdx.x & 63) < nl && c != 0.0) {
     const double BIG = 134217728.0;
     const double z = r_qnorm(((double)(int)(BIG * u1.mine()) + u2.mine()) / BIG);
-    const double postPrec = c / sigma2;
-    const double mean = postPrec * (ls.mine() / c) / (prec + postPrec);
+    const double w = lw.mine();
+    const double postPrec = w / sigma2;
+    const double mean = postPrec * (ls.mine() / w) / (prec + postPrec);
     const double sd = 1.0 / sqrt(prec + postPrec);
     v = mean + sd * z;
   }
@@ -410,7 +423,7 @@ constexpr int C_NRED = 5;
 struct ControlShared {
   MTState rng[3];                        // slot 0: wave 0, slots 1, 2: candidates
   double scratch[3][S4B_MAX_DEPTH];
-  double red[2][C_NRED][64];             // [sum | count][reducer][bin]
+  double red[3][C_NRED][64];             // [sum | count | weight][reducer][bin]
   Proposal prT, prN[3];
   int arrived, verdict;
   long long tPost, tStart0;
@@ -511,18 +524,29 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
         }
         wave_sum_bins<16>(pv, lane);
         if ((lane & 3) == 0) { const int k = wave_bin_of_lane<16>(lane); S.red[k >> 3][redIdx][k & 7] = pv[0]; }
+        if (a.wts) {   // weight totals of the first 8 bins
+          double wv8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wv8[j] = 0.0;
+          for (int b = ridx; b < a.grid; b += RT) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv8[j] += a.partWt[(size_t)j * a.grid + b];
+          }
+          wave_sum_bins<8>(wv8, lane);
+          if ((lane & 7) == 0) S.red[2][redIdx][wave_bin_of_lane<8>(lane)] = wv8[0];
+        }
         for (int k = 8; k < nbAll; ++k) {   // rare: more than 8 bins
-          double sm = 0.0, c = 0.0;
-          for (int b = ridx; b < a.grid; b += RT) { sm += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
-          sm = wave_sum(sm); c = wave_sum(c);
-          if (lane == 0) { S.red[0][redIdx][k] = sm; S.red[1][redIdx][k] = c; }
+          double sm = 0.0, c = 0.0, wt = 0.0;
+          for (int b = ridx; b < a.grid; b += RT) { sm += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; if (a.wts) wt += a.partWt[(size_t)k * a.grid + b]; }
+          sm = wave_sum(sm); c = wave_sum(c); wt = wave_sum(wt);
+          if (lane == 0) { S.red[0][redIdx][k] = sm; S.red[1][redIdx][k] = c; S.red[2][redIdx][k] = wt; }
         }
       } else {   // large tree: totals of every bin to global memory for the sequential path
         for (int k = redIdx; k < nbAll; k += C_NRED) {
-          double sm = 0.0, c = 0.0;
-          for (int b = lane; b < a.grid; b += 64) { sm += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; }
-          sm = wave_sum(sm); c = wave_sum(c);
-          if (lane == 0) { a.binSum[k] = sm; a.binCnt[k] = c; }
+          double sm = 0.0, c = 0.0, wt = 0.0;
+          for (int b = lane; b < a.grid; b += 64) { sm += a.partSum[(size_t)k * a.grid + b]; c += a.partCnt[(size_t)k * a.grid + b]; if (a.wts) wt += a.partWt[(size_t)k * a.grid + b]; }
+          sm = wave_sum(sm); c = wave_sum(c); wt = wave_sum(wt);
+          if (lane == 0) { a.binSum[k] = sm; a.binCnt[k] = c; if (a.wts) a.binWt[k] = wt; }
         }
         __threadfence();
       }
@@ -633,8 +657,18 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
         }
         binSum.load(sSum); binCnt.load(sCnt);
       }
+      WaveArrD binWt = binCnt;   // without weights the precision comes from the counts
+      if (a.wts) {
+        double sWt = 0.0;
+        if (lane < nb) {
+          sWt = S.red[2][0][lane];
+#pragma unroll
+          for (int r = 1; r < C_NRED; ++r) sWt += S.red[2][r][lane];
+        }
+        binWt.load(sWt);
+      }
       DecideWork<WaveArrD> wk;
-      wk.ll.load(0.0); wk.lc.load(0.0); wk.ls.load(0.0); wk.u1.load(0.5); wk.u2.load(0.5); wk.val.load(0.0);
+      wk.ll.load(0.0); wk.lc.load(0.0); wk.ls.load(0.0); wk.u1.load(0.5); wk.u2.load(0.5); wk.val.load(0.0); wk.lw.load(0.0);
       StepRecord rec; int32_t accepted = 0;
       // as soon as the step's last random number is drawn: which candidate (if any) started from the position the
       // generator is at now?  (posted before the leaf arithmetic so that the winner publishes meanwhile)
@@ -646,7 +680,7 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
         if (lane == 0) { S.tPost = wall_clock64(); S.tStart0 = tk0; }
 #endif
       };
-      const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &rng, &prT, tbT, binCnt, binSum, wk, &accepted, &rec, caT, post);
+      const int hwmNew = decide(curT, mu, cnt, muOld, hwmT, m, sigma, &rng, &prT, tbT, binCnt, binSum, binWt, wk, &accepted, &rec, caT, post);
 #ifdef S4B_CONTROL_TIMING
       tk2 = wall_clock64();
 #endif
@@ -1008,10 +1042,12 @@ __global__ __launch_bounds__(BLOCK) void k_stan_inputs(BartArrays a, StanArrays 
       e = resp - so;
       if (wantTrain) s.train[i] = fit;
     }
-    dstE[i] = e;
-    acc[0] += e * e;
+    // weighted likelihood (continuous.stan:358-366): sums of w e^2, X'(w e), Z'(w e); the followers read w e from s.e
+    const double we = a.wts ? a.wts[i] * e : e;
+    if (direct) dstE[i] = we; else { dstE[i] = e; if (a.wts) s.e[i] = we; }
+    acc[0] += we * e;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) if (k < s.K) acc[1 + k] += s.X[(size_t)k * a.n + i] * e;
+    for (int k = 0; k < 3; ++k) if (k < s.K) acc[1 + k] += s.X[(size_t)k * a.n + i] * we;
   }
   block_reduce_store<4>(acc, 0, 1 + (s.K < 3 ? s.K : 3), s.part, a.grid);
 }
@@ -1188,10 +1224,14 @@ class DevHip {
       c.pparent = c.slab + SF_PARENT * nc_; c.pna = c.slab + SF_NA * nc_; c.pdep = c.slab + SF_DEP * nc_; c.binA = c.slab + SF_BINA * nc_; c.binB = c.slab + SF_BINB * nc_;
       c.list = zalloc<int16_t>(nc_); c.insub = zalloc<uint8_t>(nc_);
       c.muOld = zalloc<double>(nc_); c.prop = zalloc<Proposal>(1); c.accepted = zalloc<int32_t>(1);
-      c.work = zalloc<double>((size_t)12 * nc_);
+      c.work = zalloc<double>((size_t)14 * nc_);
     }
     a.partCnt = zalloc<double>((size_t)a.binCap * a.grid); a.partSum = zalloc<double>((size_t)a.binCap * a.grid);
     a.binCnt = zalloc<double>((size_t)a.binCap); a.binSum = zalloc<double>((size_t)a.binCap);
+    if (d.weights) {
+      double* wt = alloc<double>((size_t)a.npad); HIP_OK(hipMemsetAsync(wt, 0, (size_t)a.npad * 8, stream_)); upload(wt, d.weights, (size_t)n_); a.wts = wt;
+      a.partWt = zalloc<double>((size_t)a.binCap * a.grid); a.binWt = zalloc<double>((size_t)a.binCap);
+    }
     a.rng = zalloc<MTState>(1); a.scale = zalloc<ScaleState>(1);
     int32_t* nc = alloc<int32_t>((size_t)P_); upload(nc, d.numCuts, (size_t)P_); a.numCuts = nc;
     a.trace = zalloc<StepRecord>((size_t)std::max(1, d.traceCap)); a.traceCount = zalloc<int32_t>(1); a.errFlag = zalloc<int32_t>(1);
@@ -1228,8 +1268,10 @@ class DevHip {
     gridN_ = a.grid;   // one launch geometry for every O(N) kernel: the partial buffers are sized by it
     ldsApply_ = apply_lds_bytes(nc_); ldsTree_ = tree_lds_bytes(nc_); ldsControl_ = control_lds_bytes(P_, d.model.logIntLen);
     if (ldsTree_ > 64 * 1024) {
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
     }
     if (ldsApply_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsApply_));
     if (ldsTree_ > 160 * 1024) throw std::runtime_error("node_capacity too large for the 160 KiB LDS of a CU");
@@ -1336,13 +1378,21 @@ class DevHip {
     HIP_OK(hipGraphInstantiate(&graphExec_, graph_, nullptr, nullptr, 0));
     graphTrace_ = a_.traceOn;
   }
+  void launch_tree(int t) {
+    if (a_.wts) {
+      if (t == 0) hipLaunchKernelGGL((k_tree<false, true>), dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
+      else hipLaunchKernelGGL((k_tree<true, true>), dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
+    } else {
+      if (t == 0) hipLaunchKernelGGL((k_tree<false, false>), dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
+      else hipLaunchKernelGGL((k_tree<true, false>), dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
+    }
+  }
   void sweep_eager(int thin, bool withLatents) {
     for (int k = 0; k < thin; ++k) {
       // per tree: one fused O(N) kernel (finish tree t-1, statistics of tree t) + one control kernel
       hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, -1, 0); ++launches_;
       for (int t = 0; t < T_; ++t) {
-        if (t == 0) hipLaunchKernelGGL(k_tree<false>, dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
-        else hipLaunchKernelGGL(k_tree<true>, dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
+        launch_tree(t);
         hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, t, t + 1 < T_ ? t + 1 : -1);
         launches_ += 2;
       }
@@ -1362,8 +1412,7 @@ class DevHip {
         hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, -1, 0); ++launches_;
         for (int t = 0; t < T_; ++t) {
           HIP_OK(hipEventRecord(ev[e++], stream_));
-          if (t == 0) hipLaunchKernelGGL(k_tree<false>, dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
-          else hipLaunchKernelGGL(k_tree<true>, dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
+          launch_tree(t);
           HIP_OK(hipEventRecord(ev[e++], stream_));
           HIP_OK(hipEventRecord(ev[e++], stream_));
           hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, t, t + 1 < T_ ? t + 1 : -1);
@@ -1489,8 +1538,9 @@ class DevHip {
   }
   void reduce_pipeline(int mode, int wantTrain, int direct) {
     hipLaunchKernelGGL(k_stan_inputs, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, mode, wantTrain, direct); ++launches_;
-    for (int k0 = 3; k0 < K_; k0 += 4) { hipLaunchKernelGGL(k_xt_e, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, k0, direct); ++launches_; }
-    if (s_.numChunks) { hipLaunchKernelGGL(k_zt_chunks, dim3(s_.numChunks), dim3(BLOCK), 0, stream_, s_, direct); ++launches_; }
+    const int fromE = (direct || a_.wts) ? 1 : 0;   // with weights the weighted residual lives in s.e in both modes
+    for (int k0 = 3; k0 < K_; k0 += 4) { hipLaunchKernelGGL(k_xt_e, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, k0, fromE); ++launches_; }
+    if (s_.numChunks) { hipLaunchKernelGGL(k_zt_chunks, dim3(s_.numChunks), dim3(BLOCK), 0, stream_, s_, fromE); ++launches_; }
     hipLaunchKernelGGL(k_stan_finalize, dim3(1), dim3(BLOCK), 0, stream_, a_, s_, gridN_); ++launches_;
   }
   void fetch_out(double* cX, double* cZ, double* s0) {

@@ -71,6 +71,7 @@ class Stan4bartFit:
     samplers: list = field(default_factory=list)   # live samplers holding the kept trees (bart_args keepTrees)
     trees: Optional[list] = None
     callback: Optional[np.ndarray] = None   # [len(result), iterations, chains]
+    weights: Optional[np.ndarray] = None    # observation weights of the training sample
 
     # ------------------------------------------------------------------ helpers
     def _get(self, name: str, include_warmup, only_warmup):
@@ -251,7 +252,10 @@ class Stan4bartFit:
                 result = (rng.random(result.shape) < result).astype(np.float64)
             else:
                 sig = self._get("stan", include_warmup, only_warmup)[self.par_names.index("aux.1")]   # [iter, chain]
-                result = result + rng.standard_normal(result.shape) * sig[None]
+                sd = sig[None]
+                if sample == "train" and self.weights is not None:     # reference R/generics.R:452-459: sd = sigma sqrt(1 / w)
+                    sd = sd * np.sqrt(1.0 / self.weights)[:, None, None]
+                result = result + rng.standard_normal(result.shape) * sd
         return done(result)
 
     # ------------------------------------------------------------------ fitted
@@ -416,4 +420,5 @@ def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=N
         X=Xa, X_means=np.asarray(args.extras["xbar"]), X_test=None if X_test is None else np.asarray(X_test, dtype=np.float64),
         terms=terms, terms_test=terms_test, offset=None if offset is None else np.asarray(offset, dtype=np.float64),
         offset_test=None if offset_test is None else np.asarray(offset_test, dtype=np.float64), offset_type=offset_type,
-        range_bart=np.stack([r["range.bart"] for r in results], axis=1), samplers=samplers, callback=smp["callback"])
+        range_bart=np.stack([r["range.bart"] for r in results], axis=1), samplers=samplers, callback=smp["callback"],
+        weights=None if kw.get("weights") is None else np.asarray(kw["weights"], dtype=np.float64))

@@ -206,3 +206,19 @@ def test_predict_equals_extract(hip_lib, family):
     s.free()
     np.testing.assert_allclose(ptrain, r["bart"]["train"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(ptest, r["bart"]["test"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(stan_args={"hmc_mode": 1}), dict(n=1003, T=20, ranef=False, warmup=10, iter=25),
+                                dict(n=3000, T=6, warmup=15, iter=30, ranef=False, bart_args={"base": 0.99, "power": 0.45, "k": 0.5})], ids=str)
+def test_observation_weights(oracle_lib, hip_lib, kw):
+    """weights in both blocks (weighted leaf statistics, weighted Stan likelihood); the last case has > 8 bins, i.e.
+    several bin passes of the weighted kernel."""
+    kw_o = {k: v for k, v in kw.items() if k != "stan_args"}
+    n = kw.get("n", 100)
+    w = np.random.default_rng(5).uniform(0.3, 3.0, n)
+    a = run_chain(oracle_lib, "orc_", friedman_case(weights=w, **kw_o)[0])
+    b = run_chain(hip_lib, "s4b_", friedman_case(weights=w, **kw)[0])
+    assert_chain_parity(a, b)
+    c = run_chain(hip_lib, "s4b_", friedman_case(**kw)[0])
+    d = run_chain(hip_lib, "s4b_", friedman_case(weights=np.ones(n), **kw)[0])
+    np.testing.assert_array_equal(d["trace"], c["trace"])          # unit weights == no weights
