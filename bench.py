@@ -119,7 +119,11 @@ def main():
     from stan4bart_amd.fit import chain_seeds
     from stan4bart_amd.parallel import all_gather_array, init_process_group
 
-    rank, local_rank, world = init_process_group()
+    # S4B_BENCH_BACKEND=gloo + S4B_BENCH_ONE_DEVICE=1: rehearsal of the N-rank path on a single-GPU box (all ranks share
+    # device 0, the collectives run over gloo); the driver's real runs use the default: one GPU per rank, RCCL
+    rank, local_rank, world = init_process_group(os.environ.get("S4B_BENCH_BACKEND"))
+    if os.environ.get("S4B_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -147,7 +151,7 @@ def main():
     c1 = sampler.get_counters()
     barrier()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt_max = float(t.item())
     else:
