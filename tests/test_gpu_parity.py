@@ -222,3 +222,16 @@ def test_observation_weights(oracle_lib, hip_lib, kw):
     c = run_chain(hip_lib, "s4b_", friedman_case(**kw)[0])
     d = run_chain(hip_lib, "s4b_", friedman_case(weights=np.ones(n), **kw)[0])
     np.testing.assert_array_equal(d["trace"], c["trace"])          # unit weights == no weights
+
+
+@pytest.mark.parametrize("P", [100, 140])
+def test_config5_shape_many_predictors_and_groups(oracle_lib, hip_lib, P):
+    """BASELINE config 5 shape at reduced n: P = 100 predictors (140: beyond the two register tables), 200 groups with
+    random slopes (q = 400), T trees."""
+    from test_host_logic import _c5_shape_case
+    args = _c5_shape_case(1500, P, 12, 200, 5, 10)
+    a = run_chain(oracle_lib, "orc_", args)
+    b = run_chain(hip_lib, "s4b_", args)
+    assert_chain_parity(a, b)
+    used = np.flatnonzero(a["sample"]["bart"]["varcount"].sum(axis=1))
+    assert used.max() >= 64          # rules on predictors held in the second table / in memory were proposed and accepted

@@ -225,3 +225,24 @@ def test_observation_weights_match_oracle(oracle_lib, emul_lib, kw):
     d = run_chain(emul_lib, "emu_", friedman_case(weights=np.ones(n), **kw)[0])
     np.testing.assert_array_equal(d["trace"], c["trace"])
     np.testing.assert_allclose(d["sample"]["bart"]["train"], c["sample"]["bart"]["train"], rtol=1e-9, atol=1e-9)
+
+
+def _c5_shape_case(n, P, T, n_g1, warmup, iter, **kw):
+    """BASELINE config 5 shape: P BART predictors, (1 + X4 | g.1) with many groups (q = 2 n_g1)."""
+    from stan4bart_amd import GroupTerm, generate_friedman_data, make_sampler_args
+    d = generate_friedman_data(n, ranef=True, causal=True, p=P + 1, n_g1=n_g1)
+    x = d["x"]
+    xb = x[:, [j for j in range(P + 1) if j != 3]]
+    return make_sampler_args(d["y"], xb, X=np.column_stack([x[:, 3], d["z"]]), groups=[GroupTerm(d["g1"], x[:, 3], "g.1")],
+                             iter=iter, warmup=warmup, bart_args={"n.trees": T}, **kw)
+
+
+@pytest.mark.parametrize("P", [100, 140])
+def test_config5_shape_many_predictors_and_groups(oracle_lib, emul_lib, P):
+    """more than 64 / more than 128 BART predictors (register-table, second register and memory paths of the device's
+    predictor tables) and 200 groups with random slopes (q = 400)."""
+    args = _c5_shape_case(1500, P, 12, 200, 5, 10)
+    a = run_chain(oracle_lib, "orc_", args)
+    b = run_chain(emul_lib, "emu_", args)
+    assert_chain_parity(a, b)
+    assert a["sample"]["bart"]["varcount"].shape[0] == P
