@@ -1,0 +1,57 @@
+# Emits reference goldens for the hot path, for anyone with R and the CRAN packages stan4bart + dbarts installed
+# (neither is available in the build image; see DESIGN.md §2 "parity unpinned").
+#
+#   Rscript tools/make_goldens.R tests/golden/reference_c1.json
+#
+# Setting: the reference's own reproducibility test (tests/testthat/test-05-rng.R:11-27) — Friedman data n = 100 from
+# inst/common/friedmanData.R (seed 99 inside the generator), formula
+#   y ~ bart(. - g.1 - g.2 - X4 - z) + X4 + z + (1 + X4 | g.1) + (1 | g.2),
+# seed = 12345, chains = 1, cores = 1, warmup = 7, iter = 13, bart_args = list(n.trees = 11, keepTrees = TRUE).
+# tests/test_reference_goldens.py compares the oracle (and, on a GPU box, the HIP path) with the file when it exists:
+# data (generator parity), per-draw sigma / BART fits / variable counts / Stan rows, and the kept trees.
+suppressPackageStartupMessages({ library(stan4bart); library(dbarts) })
+args <- commandArgs(trailingOnly = TRUE)
+out <- if (length(args) >= 1L) args[1L] else "reference_c1.json"
+
+source(system.file("common", "friedmanData.R", package = "stan4bart"), local = TRUE)
+testData <- generateFriedmanData(100, TRUE, TRUE, FALSE)
+df <- with(testData, data.frame(x, g.1, g.2, y, z))
+
+fit <- stan4bart(y ~ bart(. - g.1 - g.2 - X4 - z) + X4 + z + (1 + X4 | g.1) + (1 | g.2), df,
+                 verbose = -1L, warmup = 7, iter = 13, seed = 12345L, chains = 1, cores = 1,
+                 bart_args = list(n.trees = 11, keepTrees = TRUE))
+
+trees <- extract(fit, "trees")
+num <- function(x) as.numeric(x)
+golden <- list(
+  versions    = list(R = R.version.string, stan4bart = as.character(packageVersion("stan4bart")),
+                     dbarts = as.character(packageVersion("dbarts"))),
+  settings    = list(n = 100L, seed = 12345L, warmup = 7L, iter = 13L, n.trees = 11L, chains = 1L),
+  data        = list(x = num(testData$x), x_dim = dim(testData$x), y = num(testData$y), z = num(testData$z),
+                     g1 = as.integer(testData$g.1), g2 = as.integer(testData$g.2)),
+  par_names   = dimnames(fit$stan)[[1L]],
+  stan        = num(fit$stan[,,1L]), stan_dim = dim(fit$stan)[1L:2L],
+  stan_warmup = num(fit$warmup$stan[,,1L]),
+  sigma       = num(extract(fit, "sigma")),
+  bart_train  = num(fit$bart_train[,,1L]), bart_train_dim = dim(fit$bart_train)[1L:2L],
+  varcount    = as.integer(fit$bart_varcount[,,1L]),
+  range_bart  = num(fit$range.bart[,1L]),
+  trees       = list(sample = as.integer(trees$sample), tree = as.integer(trees$tree), n = as.integer(trees$n),
+                     var = as.integer(trees$var), value = num(trees$value))
+)
+
+to_json <- function(x, digits = 17L) {
+  if (is.list(x)) {
+    nm <- names(x)
+    body <- vapply(seq_along(x), function(i) paste0('"', nm[i], '": ', to_json(x[[i]], digits)), "")
+    paste0("{", paste(body, collapse = ", "), "}")
+  } else if (is.character(x)) {
+    if (length(x) == 1L) paste0('"', x, '"') else paste0("[", paste0('"', x, '"', collapse = ", "), "]")
+  } else {
+    v <- if (is.integer(x)) as.character(x) else formatC(x, digits = digits, format = "g")
+    v[!is.finite(x)] <- "null"
+    if (length(x) == 1L) v else paste0("[", paste(v, collapse = ", "), "]")
+  }
+}
+writeLines(to_json(golden), out)
+cat("wrote", out, "\n")
