@@ -16,6 +16,8 @@
 #include <cmath>
 #include <cstdint>
 #include <functional>
+#include <chrono>
+#include <cstdio>
 #include <limits>
 #include <stdexcept>
 #include <string>
@@ -27,12 +29,22 @@ namespace s4b {
 class Tape {
  public:
   struct Op { double val; int a, b; double da, db; };
-  std::vector<Op> ops;
+  // flat storage with an explicit fill count: recording a node is a bounds check and one store (the tape is re-recorded
+  // for every gradient, a few hundred nodes, hundreds of gradients per Gibbs iteration)
+  struct Ops {
+    std::vector<Op> buf; size_t n = 0;
+    size_t size() const { return n; }
+    void clear() { n = 0; }
+    void reserve(size_t k) { if (buf.size() < k) buf.resize(k); }
+    Op& operator[](size_t i) { return buf[i]; }
+    const Op& operator[](size_t i) const { return buf[i]; }
+    int push(const Op& o) { if (n == buf.size()) buf.resize(buf.empty() ? 1024 : 2 * buf.size()); buf[n] = o; return (int)n++; }
+  } ops;
   std::vector<double> adj;
   void clear() { ops.clear(); }
-  int leaf(double v) { ops.push_back({v, -1, -1, 0, 0}); return (int)ops.size() - 1; }
-  int un(int a, double v, double da) { ops.push_back({v, a, -1, da, 0}); return (int)ops.size() - 1; }
-  int bin(int a, int b, double v, double da, double db) { ops.push_back({v, a, b, da, db}); return (int)ops.size() - 1; }
+  int leaf(double v) { return ops.push({v, -1, -1, 0, 0}); }
+  int un(int a, double v, double da) { return ops.push({v, a, -1, da, 0}); }
+  int bin(int a, int b, double v, double da, double db) { return ops.push({v, a, b, da, db}); }
   double val(int i) const { return ops[(size_t)i].val; }
   // propagate: caller seeds adj (size = ops.size()) then calls backward()
   void backward() {
@@ -130,7 +142,9 @@ class HostModel {
     for (int k = 0; k < sp.n_z_beta; ++k) z_beta.push_back(Q(pos++));
     // lower-bounded blocks of the shrinkage priors (continuous.stan:266-270; arrays of vectors are read array-major)
     auto lb0e = [&](int idx) { TV x = Q(idx); if (jacobian) lp = lp + x; return texp(x); };
-    std::vector<TV> global, caux, lambda1, mix; std::vector<std::vector<TV>> local((size_t)sp.hs);
+    std::vector<TV>& global = sGlobal_; std::vector<TV>& caux = sCaux_; std::vector<TV>& lambda1 = sLambda_; std::vector<TV>& mix = sMix_;
+    std::vector<std::vector<TV>>& local = sLocal_;
+    global.clear(); caux.clear(); lambda1.clear(); mix.clear(); local.resize((size_t)sp.hs); for (auto& v : local) v.clear();
     for (int j = 0; j < sp.hs; ++j) global.push_back(lb0e(pos++));
     for (int j = 0; j < sp.hs; ++j) for (int k = 0; k < sp.K; ++k) local[(size_t)j].push_back(lb0e(pos++));
     if (sp.hs > 0) caux.push_back(lb0e(pos++));
@@ -212,14 +226,14 @@ class HostModel {
       else if (sp.prior_dist_for_aux == 2) {
         double nu = sp.prior_df_for_aux;
         TV tt = tlog(tsquare(aux_unscaled) / nu + 1.0) * (-(nu + 1.0) / 2.0);
-        lp = lp + (tt + (std::lgamma((nu + 1.0) / 2.0) - std::lgamma(nu / 2.0) - 0.5 * std::log(nu * M_PI))) - log_half;
+        lp = lp + (tt + (lg((nu + 1.0) / 2.0) - lg(nu / 2.0) - 0.5 * std::log(nu * M_PI))) - log_half;
       } else lp = lp - aux_unscaled;
     }
     if (sp.prior_dist >= 1) for (auto& z : z_beta) lp = lp + tstd_normal_lpdf(z);
     {
       const double log_half = -0.693147180559945286;
       auto half_normal = [&](const std::vector<TV>& v) { for (auto& x : v) lp = lp + tstd_normal_lpdf(x); lp = lp - log_half; };
-      auto inv_gamma = [&](TV x, double al, double be) { lp = lp + (tlog(x) * (-(al + 1.0)) - (1.0 / x) * be + (al * std::log(be) - std::lgamma(al))); };
+      auto inv_gamma = [&](TV x, double al, double be) { lp = lp + (tlog(x) * (-(al + 1.0)) - (1.0 / x) * be + (al * std::log(be) - lg(al))); };
       if (sp.hs > 0) {
         half_normal(local[0]);
         for (int k = 0; k < sp.K; ++k) inv_gamma(local[1][(size_t)k], 0.5 * sp.prior_df[(size_t)k], 0.5 * sp.prior_df[(size_t)k]);
@@ -234,7 +248,7 @@ class HostModel {
       for (auto& x : mix) lp = lp - x;   // exponential_lpdf(mix | 1)
       if (sp.n_lambda) {                 // chi_square_lpdf(one_over_lambda | prior_df[1])
         double nu = sp.prior_df[0];
-        lp = lp + (tlog(lambda1[0]) * (0.5 * nu - 1.0) - lambda1[0] * 0.5 - (0.5 * nu * std::log(2.0) + std::lgamma(0.5 * nu)));
+        lp = lp + (tlog(lambda1[0]) * (0.5 * nu - 1.0) - lambda1[0] * 0.5 - (0.5 * nu * std::log(2.0) + lg(0.5 * nu)));
       }
     }
     for (auto& z : z_b) lp = lp + tstd_normal_lpdf(z);
@@ -242,19 +256,19 @@ class HostModel {
     int pos_reg = 0, pos_rho = 0;
     for (int i = 0; i < sp.t; ++i) if (sp.p[(size_t)i] > 1) {
       int m = sp.p[(size_t)i] - 1;
-      std::vector<double> s1((size_t)m), s2((size_t)m);
+      std::vector<double>& s1 = sS1_; std::vector<double>& s2 = sS2_; s1.assign((size_t)m, 0.0); s2.assign((size_t)m, 0.0);
       double nu = sp.regularization[(size_t)pos_reg++] + 0.5 * (sp.p[(size_t)i] - 2);
       s1[0] = nu; s2[0] = nu;
       for (int j = 2; j <= m; ++j) { nu -= 0.5; s1[(size_t)j - 1] = 0.5 * j; s2[(size_t)j - 1] = nu; }
       for (int j = 0; j < m; ++j) {
         TV r = rho[(size_t)(pos_rho + j)];
-        double lbeta = std::lgamma(s1[(size_t)j]) + std::lgamma(s2[(size_t)j]) - std::lgamma(s1[(size_t)j] + s2[(size_t)j]);
+        double lbeta = lg(s1[(size_t)j]) + lg(s2[(size_t)j]) - lg(s1[(size_t)j] + s2[(size_t)j]);
         lp = lp + (tlog(r) * (s1[(size_t)j] - 1.0) + tlog1m(r) * (s2[(size_t)j] - 1.0) - lbeta);
       }
       pos_rho += m;
     }
-    for (int j = 0; j < sp.len_conc; ++j) lp = lp + (tlog(zeta[(size_t)j]) * (sp.delta[(size_t)j] - 1.0) - zeta[(size_t)j] - std::lgamma(sp.delta[(size_t)j]));
-    for (int j = 0; j < sp.t; ++j) lp = lp + (tlog(tau[(size_t)j]) * (sp.shape[(size_t)j] - 1.0) - tau[(size_t)j] - std::lgamma(sp.shape[(size_t)j]));
+    for (int j = 0; j < sp.len_conc; ++j) lp = lp + (tlog(zeta[(size_t)j]) * (sp.delta[(size_t)j] - 1.0) - zeta[(size_t)j] - lg(sp.delta[(size_t)j]));
+    for (int j = 0; j < sp.t; ++j) lp = lp + (tlog(tau[(size_t)j]) * (sp.shape[(size_t)j] - 1.0) - tau[(size_t)j] - lg(sp.shape[(size_t)j]));
     F.lp = lp;
   }
 
@@ -262,7 +276,13 @@ class HostModel {
     ++gradEvals;
     Fwd& F = fwd_; std::vector<int>& qidx = qidx_;
     F.wantConstrained = false;
+#ifdef S4B_NUTS_TIMING
+    const auto t0 = std::chrono::steady_clock::now();
+#endif
     forward(tape_, qv, F, qidx, true);
+#ifdef S4B_NUTS_TIMING
+    const auto t1 = std::chrono::steady_clock::now();
+#endif
     std::vector<double>& beta = bufBeta_; std::vector<double>& b = bufB_; std::vector<double>& gX = bufGX_; std::vector<double>& gZ = bufGZ_;
     beta.resize((size_t)sp.K); b.resize((size_t)sp.q); gX.assign((size_t)sp.K, 0.0); gZ.assign((size_t)sp.q, 0.0);
     for (int k = 0; k < sp.K; ++k) beta[(size_t)k] = F.beta[(size_t)k].v();
@@ -276,9 +296,17 @@ class HostModel {
     tape_.adj[(size_t)F.sigma.i] += ss / (s2 * sigma) - N / sigma;
     for (int k = 0; k < sp.K; ++k) tape_.adj[(size_t)F.beta[(size_t)k].i] += gX[(size_t)k] / s2;
     for (int j = 0; j < sp.q; ++j) tape_.adj[(size_t)F.b[(size_t)j].i] += gZ[(size_t)j] / s2;
+#ifdef S4B_NUTS_TIMING
+    const auto t2 = std::chrono::steady_clock::now();
+#endif
     tape_.backward();
     grad.resize((size_t)sp.D);
     for (int i = 0; i < sp.D; ++i) grad[(size_t)i] = tape_.adj[(size_t)qidx[(size_t)i]];
+#ifdef S4B_NUTS_TIMING
+    { const auto t3 = std::chrono::steady_clock::now(); auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      tFwd_ += us(t0, t1); tLik_ += us(t1, t2); tBwd_ += us(t2, t3);
+      if (gradEvals % 5000 == 0) std::fprintf(stderr, "S4B gradient us: forward %.2f lik %.2f backward %.2f (tape %zu nodes)\n", tFwd_ / gradEvals, tLik_ / gradEvals, tBwd_ / gradEvals, tape_.ops.size()); }
+#endif
     return F.lp.v() + ll;
   }
 
@@ -296,6 +324,19 @@ class HostModel {
   }
 
  private:
+  // the log-gamma constants of the priors depend on the data only: computed once, reused by every gradient
+  mutable std::vector<std::pair<double, double>> lgMemo_;
+  double lg(double x) const {
+    for (const auto& e : lgMemo_) if (e.first == x) return e.second;
+    const double v = std::lgamma(x);
+    if (lgMemo_.size() < 64) lgMemo_.emplace_back(x, v);
+    return v;
+  }
+  mutable std::vector<TV> sGlobal_, sCaux_, sLambda_, sMix_, sT_, sPi_; mutable std::vector<std::vector<TV>> sLocal_;
+  mutable std::vector<double> sS1_, sS2_; mutable std::vector<int> sIdx_;
+#ifdef S4B_NUTS_TIMING
+  double tFwd_ = 0, tLik_ = 0, tBwd_ = 0;
+#endif
   Tape tape_;
   mutable std::vector<TV> w_[6];
   Fwd fwd_; std::vector<int> qidx_; std::vector<double> bufBeta_, bufB_, bufGX_, bufGZ_;
@@ -315,12 +356,12 @@ class HostModel {
       TV A = tau[(size_t)i] * sp.scale[(size_t)i] * dispersion;
       if (nc == 1) { out.push_back(A); continue; }
       TV zero{&tp, tp.leaf(0.0)};
-      std::vector<TV> T((size_t)(nc * nc), zero);
+      std::vector<TV>& T = sT_; T.assign((size_t)(nc * nc), zero);
       auto at = [&](int r, int c) -> TV& { return T[(size_t)(r * nc + c)]; };
       TV trace = tsquare(A) * (double)nc;
       TV sum_pi = zeta[(size_t)zeta_mark];
       for (int j = 1; j < nc; ++j) sum_pi = sum_pi + zeta[(size_t)(zeta_mark + j)];
-      std::vector<TV> pi;
+      std::vector<TV>& pi = sPi_; pi.clear();
       for (int j = 0; j < nc; ++j) pi.push_back(zeta[(size_t)(zeta_mark + j)] / sum_pi);
       zeta_mark += nc;
       TV std_dev = tsqrt(pi[0] * trace);
@@ -352,7 +393,7 @@ class HostModel {
         for (int s = 0; s < sp.l[(size_t)i]; ++s) b.push_back(th[(size_t)tm] * z_b[(size_t)(b_mark + s)]);
         b_mark += sp.l[(size_t)i]; tm += 1;
       } else {
-        std::vector<int> idx((size_t)(nc * nc), -1);   // theta_L index of T[r][c], column-major lower triangle
+        std::vector<int>& idx = sIdx_; idx.assign((size_t)(nc * nc), -1);   // theta_L index of T[r][c], column-major lower triangle
         for (int c = 0; c < nc; ++c) for (int r = c; r < nc; ++r) idx[(size_t)(r * nc + c)] = tm++;
         for (int j = 0; j < sp.l[(size_t)i]; ++j) {
           for (int r = 0; r < nc; ++r) {
