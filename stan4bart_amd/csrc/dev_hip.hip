@@ -133,9 +133,13 @@ __device__ __forceinline__ TreeLds carve_tree(unsigned char* base, int nc) {
 template <int NB, bool APPLY, bool WEIGHTED>
 __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const TreeLds& L, int root, int prevRoot, int prevAcc, int base,
                                           int nbTotal) {
-  double accS[NB]; int accN[NB]; double accW[WEIGHTED ? NB : 1];
+  // per-thread bin counts are small (a thread sees at most 4 * 255 observations, enforced by the launch geometry): two
+  // 16-bit counters per register, unpacked before the block reduction
+  double accS[NB]; unsigned accP[(NB + 1) / 2]; double accW[WEIGHTED ? NB : 1];
 #pragma unroll
-  for (int k = 0; k < NB; ++k) { accS[k] = 0.0; accN[k] = 0; if (WEIGHTED) accW[k] = 0.0; }
+  for (int k = 0; k < NB; ++k) { accS[k] = 0.0; if (WEIGHTED) accW[k] = 0.0; }
+#pragma unroll
+  for (int k = 0; k < (NB + 1) / 2; ++k) accP[k] = 0u;
   const double* __restrict__ W = a.wts;
   const int64_t nQuads = (a.n + 3) >> 2;
   const uint16_t* __restrict__ leafPlane = a.leaf + (size_t)t * a.npad;
@@ -143,29 +147,28 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
   double* __restrict__ R = a.R;
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
   int64_t qd = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  // software prefetch: the loads of the next quad are issued before the current one is processed
-  double2 r01, r23; us4_t lf4, pl4; double2 w01 = make_double2(1.0, 1.0), w23 = make_double2(1.0, 1.0);
-  if (qd < nQuads) {
-    const int64_t i0 = qd << 2;
-    r01 = *reinterpret_cast<const double2*>(R + i0); r23 = *reinterpret_cast<const double2*>(R + i0 + 2);
-    if (WEIGHTED) { w01 = *reinterpret_cast<const double2*>(W + i0); w23 = *reinterpret_cast<const double2*>(W + i0 + 2); }
-    lf4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(leafPlane + i0));
-    if (APPLY) pl4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(prevPlane + i0));
-  }
+  // software pipeline, two quads ahead: the loads of quads q + stride and q + 2 stride are in flight while quad q is processed
+  struct Quad { double2 r01, r23; us4_t lf4, pl4; double2 w01, w23; };
+  auto fetch = [&](int64_t q, Quad& o) {
+    if (q < nQuads) {
+      const int64_t i0 = q << 2;
+      o.r01 = *reinterpret_cast<const double2*>(R + i0); o.r23 = *reinterpret_cast<const double2*>(R + i0 + 2);
+      if (WEIGHTED) { o.w01 = *reinterpret_cast<const double2*>(W + i0); o.w23 = *reinterpret_cast<const double2*>(W + i0 + 2); }
+      o.lf4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(leafPlane + i0));
+      if (APPLY) o.pl4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(prevPlane + i0));
+    }
+  };
+  Quad qa, qb;
+  qa.w01 = qa.w23 = qb.w01 = qb.w23 = make_double2(1.0, 1.0);
+  fetch(qd, qa); fetch(qd + stride, qb);
   for (; qd < nQuads; qd += stride) {
     const int64_t i0 = qd << 2;
-    double rr[4] = {r01.x, r01.y, r23.x, r23.y};
-    const double ww[4] = {w01.x, w01.y, w23.x, w23.y};
-    const unsigned lf[4] = {lf4.x, lf4.y, lf4.z, lf4.w};
-    unsigned pl[4] = {pl4.x, pl4.y, pl4.z, pl4.w};
-    const int64_t qn = qd + stride;
-    if (qn < nQuads) {
-      const int64_t j0 = qn << 2;
-      r01 = *reinterpret_cast<const double2*>(R + j0); r23 = *reinterpret_cast<const double2*>(R + j0 + 2);
-      if (WEIGHTED) { w01 = *reinterpret_cast<const double2*>(W + j0); w23 = *reinterpret_cast<const double2*>(W + j0 + 2); }
-      lf4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(leafPlane + j0));
-      if (APPLY) pl4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(prevPlane + j0));
-    }
+    double rr[4] = {qa.r01.x, qa.r01.y, qa.r23.x, qa.r23.y};
+    const double ww[4] = {qa.w01.x, qa.w01.y, qa.w23.x, qa.w23.y};
+    const unsigned lf[4] = {qa.lf4.x, qa.lf4.y, qa.lf4.z, qa.lf4.w};
+    unsigned pl[4] = {qa.pl4.x, qa.pl4.y, qa.pl4.z, qa.pl4.w};
+    qa = qb;
+    fetch(qd + 2 * stride, qb);
     const int valid = (a.n - i0) >= 4 ? 4 : (int)(a.n - i0);
     if (APPLY) {
 #pragma unroll
@@ -214,13 +217,16 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
       for (int k = 0; k < NB; ++k) {
         const bool m = (ba == k) | (bb == k);
         accS[k] += m ? r : 0.0;
-        accN[k] += m ? 1 : 0;
+        accP[k >> 1] += m ? ((k & 1) ? 65536u : 1u) : 0u;
         if (WEIGHTED) accW[k] += m ? ww[e] : 0.0;
       }
     }
   }
   // block reduction, fixed order: transposed halving inside each wave, then waves 0..3 in order
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int accN[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) accN[k] = (int)((accP[k >> 1] >> (16 * (k & 1))) & 0xffffu);
   wave_sum_bins<NB>(accS, lane);
   wave_sum_bins<NB>(accN, lane);
   if (WEIGHTED) wave_sum_bins<WEIGHTED ? NB : 1>(accW, lane);
@@ -1181,6 +1187,9 @@ class DevHip {
     a.grid = (int)std::max<int64_t>(1, (nQuads + (int64_t)BLOCK * 2 - 1) / ((int64_t)BLOCK * 2));
     if (a.grid > 512) a.grid = (int)std::min<int64_t>(1024, std::max<int64_t>(512, (nQuads + (int64_t)BLOCK * 8 - 1) / ((int64_t)BLOCK * 8)));
     if (const char* g = getenv("S4B_GRID")) { int v = atoi(g); if (v >= 1 && v <= GRID_MAX) a.grid = v; }
+    // the tree kernel keeps 16-bit per-thread bin counts: at most 255 quads per thread
+    while ((nQuads + (int64_t)a.grid * BLOCK - 1) / ((int64_t)a.grid * BLOCK) > 255 && a.grid < GRID_MAX) a.grid *= 2;
+    if ((nQuads + (int64_t)a.grid * BLOCK - 1) / ((int64_t)a.grid * BLOCK) > 255) throw std::invalid_argument("n is too large for one device (more than 255 quads per thread)");
     a.binCap = 2 * nc_; a.traceCap = d.traceCap;
     // ---- observation-length arrays
     uint16_t* xb = alloc<uint16_t>((size_t)P_ * a.npad);
