@@ -148,10 +148,19 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
   int64_t qd = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   // software pipeline, two quads ahead: the loads of quads q + stride and q + 2 stride are in flight while quad q is processed
-  struct Quad { double2 r01, r23; us4_t lf4, pl4; double2 w01, w23; };
+  // the first routing level of both halves is known before the loop (the root of the proposed / accepted subtree): its
+  // predictor values travel with the quad instead of being a dependent load per observation
+  const int rootVarS = L.SP[root].var, rootCutS = L.SP[root].cut, rootLS = L.SP[root].left, rootRS = L.SP[root].right;
+  const int rootVarA = (APPLY && prevAcc) ? (int)L.AP[prevRoot].var : -1;
+  const int rootCutA = APPLY ? (int)L.AP[prevRoot].cut : 0, rootLA = APPLY ? (int)L.AP[prevRoot].left : 0, rootRA = APPLY ? (int)L.AP[prevRoot].right : 0;
+  const uint16_t* __restrict__ colS = a.xbin + (size_t)(rootVarS >= 0 ? rootVarS : 0) * a.npad;
+  const uint16_t* __restrict__ colA = a.xbin + (size_t)(rootVarA >= 0 ? rootVarA : 0) * a.npad;
+  struct Quad { double2 r01, r23; us4_t lf4, pl4, xs4, xa4; double2 w01, w23; };
   auto fetch = [&](int64_t q, Quad& o) {
     if (q < nQuads) {
       const int64_t i0 = q << 2;
+      if (rootVarS >= 0) o.xs4 = *reinterpret_cast<const us4_t*>(colS + i0);
+      if (APPLY && rootVarA >= 0) o.xa4 = *reinterpret_cast<const us4_t*>(colA + i0);
       o.r01 = *reinterpret_cast<const double2*>(R + i0); o.r23 = *reinterpret_cast<const double2*>(R + i0 + 2);
       if (WEIGHTED) { o.w01 = *reinterpret_cast<const double2*>(W + i0); o.w23 = *reinterpret_cast<const double2*>(W + i0 + 2); }
       o.lf4 = __builtin_nontemporal_load(reinterpret_cast<const us4_t*>(leafPlane + i0));
@@ -167,6 +176,8 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
     const double ww[4] = {qa.w01.x, qa.w01.y, qa.w23.x, qa.w23.y};
     const unsigned lf[4] = {qa.lf4.x, qa.lf4.y, qa.lf4.z, qa.lf4.w};
     unsigned pl[4] = {qa.pl4.x, qa.pl4.y, qa.pl4.z, qa.pl4.w};
+    const unsigned xs[4] = {qa.xs4.x, qa.xs4.y, qa.xs4.z, qa.xs4.w};
+    const unsigned xa[4] = {qa.xa4.x, qa.xa4.y, qa.xa4.z, qa.xa4.w};
     qa = qb;
     fetch(qd + 2 * stride, qb);
     const int valid = (a.n - i0) >= 4 ? 4 : (int)(a.n - i0);
@@ -179,6 +190,7 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
         double muNew = na.muNew;
         if (prevAcc && e < valid && L.Ain[l]) {
           int nd = prevRoot;
+          if (rootVarA >= 0) nd = (xa[e] <= (unsigned)rootCutA) ? rootLA : rootRA;
           NodeP p = L.AP[nd];
           while (p.var >= 0) {
             const unsigned x = a.xbin[(size_t)p.var * a.npad + (size_t)(i0 + e)];
@@ -205,6 +217,7 @@ __device__ __forceinline__ void tree_pass(const BartArrays& a, int t, const Tree
       int bb = -1 - base;
       if (ok && ns.insub) {
         int nd = root;
+        if (rootVarS >= 0) nd = (xs[e] <= (unsigned)rootCutS) ? rootLS : rootRS;
         NodeP p = L.SP[nd];
         while (p.var >= 0) {
           const unsigned x = a.xbin[(size_t)p.var * a.npad + (size_t)(i0 + e)];
