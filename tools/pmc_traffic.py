@@ -14,7 +14,7 @@ def avg(db, counter):
     kcol = "kernel_name" if "kernel_name" in cols else "name"
     sel = "counter_name" if "counter_name" in cols else "pmc_name"
     val = "value" if "value" in cols else "counter_value"
-    row = c.execute(f"select count(*), avg({val}) from pmc_events where {kcol} like '%k_tree<true>%' and {sel} = ?", (counter,)).fetchone()
+    row = c.execute(f"select count(*), avg({val}) from pmc_events where {kcol} like '%k_tree<true%' and {sel} = ?", (counter,)).fetchone()
     return row
 
 
