@@ -1193,12 +1193,10 @@ class DevHip {
     a = BartArrays{};
     a.n = n_; a.npad = (n_ + 7) / 8 * 8; a.P = P_; a.T = T_; a.nc = nc_; a.nTest = nTest_; a.nTestPad = (nTest_ + 7) / 8 * 8;
     const int64_t nQuads = (n_ + 3) / 4;
-    // fixed launch geometry (=> fixed reduction order): ~8 quads per thread, between 1 and GRID_MAX workgroups;
-    // S4B_GRID overrides it (tuning experiments)
-    // measured on MI355X (profiles/r01_grid_sweep.txt): <= 512 workgroups with ~2 quads per thread while the kernel is
-    // latency-bound (n ~ 1e6), 1024 workgroups once there are >= 8 quads per thread (n ~ 1e7: 43 % of HBM peak)
-    a.grid = (int)std::max<int64_t>(1, (nQuads + (int64_t)BLOCK * 2 - 1) / ((int64_t)BLOCK * 2));
-    if (a.grid > 512) a.grid = (int)std::min<int64_t>(1024, std::max<int64_t>(512, (nQuads + (int64_t)BLOCK * 8 - 1) / ((int64_t)BLOCK * 8)));
+    // fixed launch geometry (=> fixed reduction order): one quad per thread up to 1024 workgroups (4 per CU), more quads per
+    // thread beyond; S4B_GRID overrides it (tuning experiments).  Measured on MI355X (profiles/r01_grid_sweep.txt): 1024
+    // workgroups are best both at n = 1e6 (latency-bound: 11.5 us per launch) and at n = 1e7 (52 % of HBM peak)
+    a.grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (nQuads + BLOCK - 1) / BLOCK));
     if (const char* g = getenv("S4B_GRID")) { int v = atoi(g); if (v >= 1 && v <= GRID_MAX) a.grid = v; }
     // the tree kernel keeps 16-bit per-thread bin counts: at most 255 quads per thread
     while ((nQuads + (int64_t)a.grid * BLOCK - 1) / ((int64_t)a.grid * BLOCK) > 255 && a.grid < GRID_MAX) a.grid *= 2;
