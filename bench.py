@@ -160,6 +160,12 @@ def main():
 
     prof = sampler.profile_sweep(a.profile_sweeps) if rank == 0 else None
     lf = sampler.profile_leapfrog(20) if rank == 0 else None
+    probe = None
+    if rank == 0:   # measured streaming ceiling of this device (read-only and in-place update over 1 GB)
+        po = (ctypes.c_double * 4)()
+        lib.s4b_stream_probe.restype = ctypes.c_int
+        if lib.s4b_stream_probe(ctypes.c_int32(local_rank), ctypes.c_int64(1 << 27), ctypes.c_int32(5), po) == 0:
+            probe = {"read_GBs": po[0], "update_in_place_GBs": po[1]}
     sampler.free()
     del args
     target = None
@@ -197,7 +203,9 @@ def main():
                          "tree_update": {"k_tree_us": prof["stats_us"], "k_control_us": prof["control_us"],
                                          "final_k_apply_us": prof["apply_us"], "algorithmic_bytes": 22.0 * n,
                                          "achieved_GBs_incl_control": 22.0 * n / (tree_update_us * 1e-6) / 1e9},
-                         "sweep_wall_us": prof["sweep_wall_us"]},
+                         "sweep_wall_us": prof["sweep_wall_us"],
+                         "measured_stream": probe,
+                         "frac_of_measured_update_stream": (achieved / probe["update_in_place_GBs"]) if probe else None},
         }
         # second kernel group of the path: the O(N) sums one leapfrog costs when the gradient is evaluated on the device
         # (hmc_mode 1, the reference's cost model).  The timed region above uses hmc_mode 0, where a leapfrog is O((K+q)^2)
@@ -214,6 +222,8 @@ def main():
                     target["traffic"] = json.load(f).get(str(a.target_n), {}).get("bytes_per_launch")
             except (OSError, ValueError):
                 target["traffic"] = None
+            if probe:
+                target["frac_of_measured_update_stream"] = target["achieved"] / probe["update_in_place_GBs"]
             rec["roofline_target_config"] = target
         if world == 1 and not a.no_cpu_baseline:
             v, secs = cpu_baseline(a.n, a.p, a.trees, a.cpu_iters)

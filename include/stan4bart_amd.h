@@ -210,6 +210,10 @@ int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
  * {stats, control, apply}: out[0..2] = average launch duration in microseconds, out[3..5] = launches timed,
  * out[6] = wall microseconds per sweep (events around the whole sweep, no per-launch events), out[7] = n. */
 int S4B_FN(profile_sweep)(s4b_sampler* s, int32_t n_sweeps, double out[8]);
+/* extension (measurement): plain streaming kernels over n_doubles doubles on `device` — out[0] GB/s of a read-only pass,
+ * out[1] GB/s of an in-place read + write pass (the residual's access pattern), out[2..3] their best times in us */
+int S4B_FN(stream_probe)(int32_t device, int64_t n_doubles, int32_t reps, double out[4]);
+
 /* extension (measurement): HIP-event timing of the per-leapfrog O(N) sums of the hmc_mode 1 path at the current draw.
  * out[0] us per evaluation (kernels), out[1] us including the result fetch, out[2] launches per evaluation, out[3] N,
  * out[4] algorithmic bytes per evaluation N (8K + 12z + 20) (SURVEY §8d B_lf) */

@@ -1152,9 +1152,52 @@ __global__ __launch_bounds__(BLOCK) void k_predict(const uint16_t* xb, int64_t n
 }
 
 // ------------------------------------------------------------------------------------------------
+// device stream probe (measurement only): what HBM delivers to plain streaming kernels of this shape, to put the roofline
+// fraction of the tree kernel next to a measured ceiling as well as the 8 TB/s specification
+__global__ __launch_bounds__(BLOCK) void k_probe_read(const double2* __restrict__ x, int64_t n2, double* out) {
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BLOCK) { const double2 v = x[i]; acc += v.x + v.y; }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && acc == 123.456) out[0] = acc;   // keeps the loads alive
+}
+__global__ __launch_bounds__(BLOCK) void k_probe_update(double2* __restrict__ x, int64_t n2) {   // read 16 B + write 16 B, like R
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n2; i += (int64_t)gridDim.x * BLOCK) { double2 v = x[i]; v.x += 1.0; v.y -= 1.0; x[i] = v; }
+}
+static void stream_probe(int device, int64_t nDoubles, int reps, double out[4]) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) throw std::runtime_error("stan4bart_amd: no HIP device available");
+  if (device < 0 || device >= count) throw std::runtime_error("stan4bart_amd: HIP device ordinal out of range");
+  HIP_OK(hipSetDevice(device));
+  if (nDoubles < 1024 || reps < 1) throw std::invalid_argument("stream probe: n >= 1024, reps >= 1");
+  double2* x = nullptr; double* o = nullptr; hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+  const int64_t n2 = nDoubles / 2;
+  HIP_OK(hipMalloc(&x, (size_t)n2 * 16)); HIP_OK(hipMalloc(&o, 64));
+  HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  HIP_OK(hipMemsetAsync(x, 0, (size_t)n2 * 16, st));
+  auto timeit = [&](int which) {
+    float best = 1e30f;
+    for (int r = 0; r < reps + 1; ++r) {
+      HIP_OK(hipEventRecord(e0, st));
+      if (which == 0) hipLaunchKernelGGL(k_probe_read, dim3(2048), dim3(BLOCK), 0, st, x, n2, o);
+      else hipLaunchKernelGGL(k_probe_update, dim3(2048), dim3(BLOCK), 0, st, x, n2);
+      HIP_OK(hipEventRecord(e1, st)); HIP_OK(hipStreamSynchronize(st));
+      float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0 && ms < best) best = ms;
+    }
+    return (double)best;
+  };
+  const double msR = timeit(0), msU = timeit(1);
+  out[0] = (double)n2 * 16.0 / (msR * 1e-3) / 1e9;          // GB/s, read only
+  out[1] = (double)n2 * 32.0 / (msU * 1e-3) / 1e9;          // GB/s, read + write in place
+  out[2] = msR * 1e3; out[3] = msU * 1e3;
+  (void)hipFree(x); (void)hipFree(o); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
+}
+
+// ------------------------------------------------------------------------------------------------
 class DevHip {
  public:
   DevHip() {}
+  static void probe_stream(int device, int64_t nDoubles, int reps, double out[4]) { stream_probe(device, nDoubles, reps, out); }
   ~DevHip() {
     if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
     if (graph_) (void)hipGraphDestroy(graph_);
