@@ -968,37 +968,162 @@ __device__ double lower_trunc_std_normal(MTState* rng, double lower) {
   }
   return x;
 }
-constexpr int LAT_CHUNK = 2048;
-__global__ __launch_bounds__(BLOCK) void k_latents(BartArrays a) {
-  __shared__ MTState s_rng;
-  __shared__ double s_mean[LAT_CHUNK];   // in: fit + offset, out: z
-  __shared__ unsigned char s_pos[LAT_CHUNK];
-  for (int i = threadIdx.x; i < (int)(sizeof(MTState) / 4); i += BLOCK) ((uint32_t*)&s_rng)[i] = ((const uint32_t*)a.rng)[i];
-  for (int64_t c0 = 0; c0 < a.n; c0 += LAT_CHUNK) {
-    const int len = (int)((a.n - c0) < LAT_CHUNK ? (a.n - c0) : LAT_CHUNK);
-    __syncthreads();
-    for (int j = threadIdx.x; j < len; j += BLOCK) {
-      const int64_t i = c0 + j;
-      s_mean[j] = (a.lat[i] - a.R[i]) + a.off[i];
-      s_pos[j] = a.y[i] > 0.0 ? 1 : 0;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int j = 0; j < len; ++j) {
-        const double mean = s_mean[j];
-        s_mean[j] = s_pos[j] ? mean + lower_trunc_std_normal(&s_rng, 0.0 - mean) : mean - lower_trunc_std_normal(&s_rng, mean - 0.0);
+// Lane-parallel where the stream allows it.  The heavy arithmetic of norm_rand (the AS241 quantile) only depends on the
+// stream position, not on the observation: wave 1 (producer) walks the generator ahead, window by window of 64 positions,
+// and publishes for every position k the tempered output u_k and Z_k = the normal deviate a norm_rand() starting at k would
+// return (it uses u_k, u_{k+1}).  Wave 0 (consumer) keeps the current window in registers and runs the sequential part —
+// which observation consumes how many positions — with register reads: a rejection step of the common branch is a
+// v_readlane and a compare.  The exponential-rejection branch (lower bound >= 0) reads the same uniforms through the
+// window.  Same positions, same arithmetic as the serial loop => same latents, same generator state afterwards.
+constexpr int LAT_RING = 8;
+struct LatShared {
+  uint32_t mt[2][626];          // generator blocks (MTState layout: 624 words + mti + pad): block b lives in mt[b & 1]
+  uint32_t U[LAT_RING][64];     // tempered outputs of window w in slot w % LAT_RING
+  double Z[LAT_RING][64];       // norm_rand() value for a draw starting at each position of the window
+  int produced, consumed, stop;
+};
+struct WindowRng {              // the consumer's view of the stream (absolute output index g; block 0 = the incoming state)
+  LatShared* S; int64_t g; int64_t wc; uint32_t ureg; int zlo, zhi; int32_t* errFlag;
+  __device__ __forceinline__ void need() {
+    const int64_t w = g >> 6;
+    if (w != wc) {
+      int guard = 0;
+      while (__hip_atomic_load(&S->produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= (int)w) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++guard > (1 << 24)) { *errFlag |= S4B_ERR_INTERNAL; break; }
       }
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < len; j += BLOCK) {
-      const int64_t i = c0 + j;
-      const double F = a.lat[i] - a.R[i];
-      const double nl = s_mean[j] - a.off[i];
-      a.lat[i] = nl; a.R[i] = nl - F;
+      const int lane = (int)(threadIdx.x & 63), slot = (int)(w % LAT_RING);
+      ureg = S->U[slot][lane];
+      const double z = S->Z[slot][lane];
+      zlo = __double2loint(z); zhi = __double2hiint(z);
+      wc = w;
+      if (lane == 0) __hip_atomic_store(&S->consumed, (int)w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // windows < w are free
     }
   }
+  __device__ __forceinline__ double norm() {   // norm_rand(): two positions
+    need();
+    const int l = (int)(g & 63);
+    const double z = __hiloint2double(__builtin_amdgcn_readlane(zhi, l), __builtin_amdgcn_readlane(zlo, l));
+    g += 2;
+    return z;
+  }
+};
+__device__ __forceinline__ uint32_t mt_next(WindowRng* r) {
+  r->need();
+  const uint32_t y = (uint32_t)__builtin_amdgcn_readlane((int)r->ureg, (int)(r->g & 63));
+  r->g += 1;
+  return y;
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= (y >> 18);
+  return y;
+}
+__device__ __forceinline__ double unif_fix(uint32_t raw) {   // unif_rand()'s mapping of a tempered output (rrng_hd.hpp r_unif)
+  const double half_ulp = 0.5 * 2.328306437080797e-10;
+  const double v = (double)raw * 2.3283064365386963e-10;
+  if (v <= 0.0) return half_ulp;
+  if (1.0 - v <= 0.0) return 1.0 - half_ulp;
+  return v;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_latents(BartArrays a) {
+  __shared__ LatShared S;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int mti0 = a.rng->mti;                      // 0..624: absolute output index of the first draw
+  const int64_t w0 = mti0 >> 6;
+  if (threadIdx.x == 0) { S.produced = 0; S.consumed = (int)w0; S.stop = 0; }   // windows < produced are published, windows < consumed are free
+  for (int i = threadIdx.x; i < 624; i += BLOCK) S.mt[0][i] = a.rng->mt[i];
   __syncthreads();
-  for (int i = threadIdx.x; i < (int)(sizeof(MTState) / 4); i += BLOCK) ((uint32_t*)a.rng)[i] = ((const uint32_t*)&s_rng)[i];
+  if (wv >= 2) return;
+
+  if (wv == 1) {   // ------------------------------------------------ producer
+    int genBlocks = 1;
+    // window w starts at absolute output index 64 w = 624 bw + iw (bw, iw advanced incrementally: no divisions)
+    int bw = (int)((64 * w0) / 624), iw = (int)(64 * w0 - (int64_t)bw * 624);
+    auto raw = [&]() -> uint32_t {   // tempered output of this lane's position in the window at (bw, iw); advances to the next window
+      const int bMax = iw + 63 >= 624 ? bw + 1 : bw;
+      while (genBlocks <= bMax) {   // next block = copy of the previous one, regenerated in place (whole wave)
+        uint32_t* src = S.mt[(genBlocks - 1) & 1]; uint32_t* dst = S.mt[genBlocks & 1];
+        for (int i = lane; i < 624; i += 64) dst[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        mt_regenerate_wave((MTState*)dst);   // (also writes the mti word of the buffer, unused here)
+        ++genBlocks;
+      }
+      int idx = iw + lane, b = bw;
+      if (idx >= 624) { idx -= 624; b += 1; }
+      const uint32_t v = mt_temper(S.mt[b & 1][idx]);
+      iw += 64; if (iw >= 624) { iw -= 624; bw += 1; }
+      return v;
+    };
+    int64_t w = w0;
+    uint32_t unext = raw();
+    for (;;) {
+      int guard = 0; bool stop = false;
+      for (;;) {   // ring space, or the consumer is done
+        if (__hip_atomic_load(&S.stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) { stop = true; break; }
+        if ((int)w - __hip_atomic_load(&S.consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < LAT_RING) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++guard > (1 << 24)) { *a.errFlag |= S4B_ERR_INTERNAL; stop = true; break; }
+      }
+      if (stop) break;
+      const uint32_t ucur = unext;
+      unext = raw();
+      const uint32_t unb = (uint32_t)__shfl_down((int)ucur, 1, 64);
+      const uint32_t u2raw = lane < 63 ? unb : (uint32_t)__builtin_amdgcn_readlane((int)unext, 0);
+      const double BIG = 134217728.0;
+      const double z = r_qnorm(((double)(int)(BIG * unif_fix(ucur)) + unif_fix(u2raw)) / BIG);
+      const int slot = (int)(w % LAT_RING);
+      S.U[slot][lane] = ucur; S.Z[slot][lane] = z;
+      ++w;
+      if (lane == 0) __hip_atomic_store(&S.produced, (int)w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // windows < w are published
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer (wave 0)
+  WindowRng wr; wr.S = &S; wr.g = mti0; wr.wc = -1; wr.ureg = 0u; wr.zlo = 0; wr.zhi = 0; wr.errFlag = a.errFlag;
+  const int64_t nBatches = (a.n + 63) >> 6;
+  auto load = [&](int64_t bi, double& mean, double& fOld, double& offv, int& pos) {
+    const int64_t i = (bi << 6) + lane;
+    mean = 0.0; fOld = 0.0; offv = 0.0; pos = 0;
+    if (bi < nBatches && i < a.n) { fOld = a.lat[i] - a.R[i]; offv = a.off[i]; mean = fOld + offv; pos = a.y[i] > 0.0 ? 1 : 0; }
+  };
+  double meanN, fN, offN; int posN;
+  load(0, meanN, fN, offN, posN);
+  for (int64_t bi = 0; bi < nBatches; ++bi) {
+    const double mean = meanN, fOld = fN, offv = offN; const int pos = posN;
+    load(bi + 1, meanN, fN, offN, posN);
+    const int cnt = (int)((a.n - (bi << 6)) < 64 ? (a.n - (bi << 6)) : 64);
+    const int mlo = __double2loint(mean), mhi = __double2hiint(mean);
+    double zout = 0.0;
+    for (int j = 0; j < cnt; ++j) {
+      const double m = __hiloint2double(__builtin_amdgcn_readlane(mhi, j), __builtin_amdgcn_readlane(mlo, j));
+      const int yp = __builtin_amdgcn_readlane(pos, j);
+      const double lower = yp ? 0.0 - m : m - 0.0;
+      double x;
+      if (lower < 0.0) { x = wr.norm(); while (x < lower) x = wr.norm(); }
+      else {
+        const double aa = 0.5 * (lower + sqrt(lower * lower + 4.0));
+        double u, r;
+        do { x = r_exp(&wr) / aa + lower; u = r_unif(&wr); const double d = x - aa; r = exp(-0.5 * d * d); } while (u > r);
+      }
+      const double z = yp ? m + x : m - x;
+      zout = lane == j ? z : zout;
+    }
+    const int64_t i = (bi << 6) + lane;
+    if (i < a.n) { const double nl = zout - offv; a.lat[i] = nl; a.R[i] = nl - fOld; }
+  }
+  // generator state after the last draw (lazy regeneration: a position on a block boundary stays in the old block, mti 624)
+  {
+    if (lane == 0) __hip_atomic_store(&S.stop, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int64_t g = wr.g;
+    int b = (int)(g / 624), idx = (int)(g - (int64_t)b * 624);
+    if (idx == 0 && b > 0) { b -= 1; idx = 624; }
+    // the producer never runs more than LAT_RING + 1 windows (< 624 positions) ahead: block b is still in its buffer
+    for (int k = lane; k < 624; k += 64) a.rng->mt[k] = S.mt[b & 1][k];
+    if (lane == 0) { a.rng->mti = idx; a.rng->pad = 0; }
+  }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_init_binary(BartArrays a) {   // latents 2y - 1, no tree fits yet

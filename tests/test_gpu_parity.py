@@ -235,3 +235,16 @@ def test_config5_shape_many_predictors_and_groups(oracle_lib, hip_lib, P):
     assert_chain_parity(a, b)
     used = np.flatnonzero(a["sample"]["bart"]["varcount"].sum(axis=1))
     assert used.max() >= 64          # rules on predictors held in the second table / in memory were proposed and accepted
+
+
+def test_probit_latents_long_stream(oracle_lib, hip_lib):
+    """binary response at a size where the latent draws cross many generator blocks and windows (producer / consumer
+    waves of k_latents) and both rejection branches occur; the R generator state must come out identical."""
+    from stan4bart_amd import generate_friedman_data, make_sampler_args
+    d = generate_friedman_data(6000, ranef=False, causal=True, binary=True, p=6)
+    x = d["x"]
+    args = make_sampler_args(d["y"], x[:, [0, 1, 2, 4, 5]], X=np.column_stack([x[:, 3], d["z"]]), family="binomial", iter=12, warmup=6,
+                             bart_args={"n.trees": 15})
+    a = run_chain(oracle_lib, "orc_", args, results_type=1)
+    b = run_chain(hip_lib, "s4b_", args, results_type=1)
+    assert_chain_parity(a, b, stan=False)
