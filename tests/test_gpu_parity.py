@@ -27,6 +27,8 @@ pytestmark = pytest.mark.gpu
     dict(n=1001, T=20, ranef=False, warmup=10, iter=20),
     dict(n=1002, T=20, ranef=False),
     dict(n=7, T=3, warmup=2, iter=4, ranef=False),
+    dict(T=1, warmup=10, iter=30, ranef=False),      # a single tree: no next tree to propose for while deciding
+    dict(T=2, warmup=10, iter=30),
 ], ids=str)
 def test_hip_matches_oracle(oracle_lib, hip_lib, kw):
     kw_o = {k: v for k, v in kw.items() if k != "stan_args"}

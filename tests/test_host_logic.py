@@ -246,3 +246,9 @@ def test_config5_shape_many_predictors_and_groups(oracle_lib, emul_lib, P):
     b = run_chain(emul_lib, "emu_", args)
     assert_chain_parity(a, b)
     assert a["sample"]["bart"]["varcount"].shape[0] == P
+
+
+@pytest.mark.parametrize("T", [1, 2])
+def test_one_and_two_trees(oracle_lib, emul_lib, T):
+    args, _ = friedman_case(T=T, warmup=10, iter=30, ranef=False)
+    assert_chain_parity(run_chain(oracle_lib, "orc_", args), run_chain(emul_lib, "emu_", args))
