@@ -391,13 +391,13 @@ typedef TreeCacheT<WaveArr<int16_t>> WaveCache;
 // Generator as the control wave sees it: the state array stays in LDS, the position and the 64-word window
 // around it live in registers (lane l = mt[wbase + l]), so a draw is a v_readlane plus the tempering.
 struct WaveRng {
-  MTState* st; int mti; int wbase; uint32_t win; int count;   // count: draws since open() / since it was last zeroed
-  __device__ __forceinline__ void open(MTState* s) { st = s; mti = S4B_UNI((int)s->mti); wbase = -64; win = 0u; count = 0; }
+  MTState* st; int mti; int wbase; uint32_t win; int count; int regen;   // count: draws since open() / since last zeroed; regen: the block was regenerated
+  __device__ __forceinline__ void open(MTState* s) { st = s; mti = S4B_UNI((int)s->mti); wbase = -64; win = 0u; count = 0; regen = 0; }
   __device__ __forceinline__ void close() { st->mti = mti; }
 };
 __device__ __forceinline__ uint32_t mt_next(WaveRng* r) {
   int k = r->mti;
-  if (k >= 624) { mt_regenerate_wave(r->st); k = 0; r->wbase = -64; }
+  if (k >= 624) { mt_regenerate_wave(r->st); k = 0; r->wbase = -64; r->regen = 1; }
   const int wb = k & ~63;
   if (wb != r->wbase) {
     const int idx = wb + (int)(threadIdx.x & 63);
@@ -456,7 +456,7 @@ __device__ __forceinline__ void spin_until(int* flag, int target, int32_t* errFl
 }
 __device__ __forceinline__ void rng_advance(WaveRng* r, int k) {
   int total = r->mti + k;
-  while (total > 624) { mt_regenerate_wave(r->st); total -= 624; }
+  while (total > 624) { mt_regenerate_wave(r->st); total -= 624; r->regen = 1; }
   r->mti = total; r->wbase = -64;
 }
 
@@ -719,11 +719,13 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
     }
     proposer = doPropose && winner == 0;
     if (!doPropose) {   // last tree of the sweep: only the generator goes back
-      rng.close(); S.rng[0].pad = 0;
+      if (rng.regen) {   // the 624-word block only changes when it was regenerated (every ~25 tree updates); else just the position
+        rng.close(); S.rng[0].pad = 0;
 #pragma unroll
-      for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; mtw[j] = ((const uint32_t*)&S.rng[0])[i < MTW ? i : 0]; }
+        for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; mtw[j] = ((const uint32_t*)&S.rng[0])[i < MTW ? i : 0]; }
 #pragma unroll
-      for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; if (i < MTW) ((uint32_t*)a.rng)[i] = mtw[j]; }
+        for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; if (i < MTW) ((uint32_t*)a.rng)[i] = mtw[j]; }
+      } else if (lane == 0) a.rng->mti = rng.mti;
     }
   }
   if (!proposer) {
@@ -770,11 +772,13 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
     proposal_store(prN, cN.prop, lane);
   }
   // ---- generator state of the surviving stream back to global
-  rng.close(); S.rng[slot].pad = 0;
+  if (rng.regen) {   // (see above)
+    rng.close(); S.rng[slot].pad = 0;
 #pragma unroll
-  for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; mtw[j] = ((const uint32_t*)&S.rng[slot])[i < MTW ? i : 0]; }
+    for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; mtw[j] = ((const uint32_t*)&S.rng[slot])[i < MTW ? i : 0]; }
 #pragma unroll
-  for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; if (i < MTW) ((uint32_t*)a.rng)[i] = mtw[j]; }
+    for (int j = 0; j < MTJ; ++j) { const int i = lane + j * 64; if (i < MTW) ((uint32_t*)a.rng)[i] = mtw[j]; }
+  } else if (lane == 0) a.rng->mti = rng.mti;
 #ifdef S4B_CONTROL_TIMING
   { S4B_TICK(tk4);
     if (lane == 0 && doDecide && doPropose) {
