@@ -1327,6 +1327,9 @@ class DevHip {
  public:
   DevHip() {}
   static void probe_stream(int device, int64_t nDoubles, int reps, double out[4]) { stream_probe(device, nDoubles, reps, out); }
+  // HIP's current device is per host thread: every entry point of the C-ABI binds the sampler's device first, so a sampler
+  // may be driven from any thread (chains fitted concurrently, predict from another thread)
+  void bind() { HIP_OK(hipSetDevice(device_)); }
   ~DevHip() {
     if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
     if (graph_) (void)hipGraphDestroy(graph_);

@@ -16,6 +16,7 @@ namespace s4b {
 class DevCpu {
  public:
   static void probe_stream(int, int64_t, int, double out[4]) { for (int i = 0; i < 4; ++i) out[i] = 0.0; }
+  void bind() {}
   void init_stored(int, int P) { P_ = P; }
   void init(const DevInit& d) {
     di_ = d;

@@ -249,3 +249,40 @@ def test_kept_trees_match_oracle_on_hip(oracle_lib, hip_lib):
         np.testing.assert_array_equal(ta[k], tb[k])
     np.testing.assert_allclose(ta["value"], tb["value"], rtol=1e-6, atol=1e-9)
     a.close(); b.close()
+
+
+def test_concurrent_chains_match_parallel_seeding_rule(emul_lib):
+    """cores > 1: chains run concurrently in threads, each seeded like the reference's parallel workers
+    (R/stan4bart_fit.R:515-533); every chain equals the same chain fitted alone with that seed."""
+    from stan4bart_amd import RRng, fit_worker, make_sampler_args
+    from stan4bart_amd.fit import chain_seeds
+    d, xb, X, groups, rows, groups_t = _data()
+    mk = lambda a, st: Sampler(emul_lib, "emu_", a, st)
+    fit = stan4bart(d["y"], xb, X=X, groups=groups, chains=3, cores=3, seed=42, iter=12, warmup=6, bart_args={"n.trees": 5}, make_sampler=mk)
+    assert fit.bart_train.shape == (len(d["y"]), 6, 3)
+    for c in range(3):
+        args = make_sampler_args(d["y"], xb, X=X, groups=groups, iter=12, warmup=6, bart_args={"n.trees": 5})
+        alone = fit_worker(mk, args, RRng(int(chain_seeds(42, 3)[c])))
+        np.testing.assert_array_equal(alone["sample"]["stan"], fit.stan[:, :, c])
+        np.testing.assert_array_equal(alone["sample"]["bart"]["train"], fit.bart_train[:, :, c])
+
+
+@pytest.mark.gpu
+def test_concurrent_chains_on_hip(hip_lib):
+    """three samplers driven from three host threads on one device (own stream and graph each), then used from the main
+    thread: equal to the same chains fitted one after the other."""
+    from stan4bart_amd import RRng, fit_worker, make_sampler_args
+    from stan4bart_amd.fit import chain_seeds
+    d, xb, X, groups, rows, groups_t = _data(n=3000)
+    mk = lambda a, st: Sampler(hip_lib, "s4b_", a, st)
+    fit = stan4bart(d["y"], xb, X=X, groups=groups, chains=3, cores=3, seed=42, iter=12, warmup=6,
+                    bart_args={"n.trees": 25, "keepTrees": True}, make_sampler=mk)
+    for c in range(3):
+        args = make_sampler_args(d["y"], xb, X=X, groups=groups, iter=12, warmup=6, bart_args={"n.trees": 25, "keepTrees": True})
+        alone = fit_worker(mk, args, RRng(int(chain_seeds(42, 3)[c])))
+        np.testing.assert_array_equal(alone["sample"]["stan"], fit.stan[:, :, c])
+        np.testing.assert_array_equal(alone["sample"]["bart"]["train"], fit.bart_train[:, :, c])
+    p = fit.predict(x_bart=xb[:9], X=X[:9], groups=[type(g)(np.asarray(g.levels)[:9], None if g.slopes is None else np.asarray(g.slopes)[:9], g.name)
+                                                    for g in groups], type="ev", combine_chains=False)
+    np.testing.assert_allclose(p, fit.extract("ev", combine_chains=False)[:9], rtol=1e-9, atol=1e-9)
+    fit.close()
