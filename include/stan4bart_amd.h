@@ -196,6 +196,37 @@ int S4B_FN(create_stored_bart_sampler)(const void* state, int64_t size, int32_t 
  * out is n_test x num_samples (column-major); pass out = NULL to query num_samples. */
 int S4B_FN(predict_bart)(s4b_sampler* s, const double* x_test, int64_t n_test, double* out, int64_t* num_samples);
 
+/* Sampler state as one relocatable byte string: checkpoint / resume of a chain, and the hook of the teacher-forced parity
+ * tests (state of one implementation injected into the other before every compared transition).  No reference routine
+ * does this: the reference can only re-run a chain from its seed (R/stan4bart_fit.R:33-60); what the blob holds is the
+ * state the reference keeps between two iterations of src/init.cpp:752-917 —
+ *   NUTS: current point, step size, dual-averaging scalars (stepsize_adaptation.hpp:10-65), window counters
+ *   (windowed_adaptation.hpp:29-110), Welford accumulators and inverse metric (var_adaptation.hpp:17-46), ecuyer1988 state;
+ *   BART: trees + leaf values, total fit per observation, offset, response scale, sigma, probit latents, R's generator.
+ * Layout (native endianness, every block 8-byte aligned), in this order:
+ *   s4b_state_header
+ *   double  q[D], inv_metric[D], welford_mean[D], welford_m2[D]
+ *   double  nuts[6]     = {stepsize, da_mu, da_counter, da_s_bar, da_x_bar, welford_n}
+ *   double  last_row[7] = lp__, accept_stat__, stepsize__, treedepth__, n_leapfrog__, divergent__, energy__ of the last draw
+ *   uint32  win[8]      = {num_warmup, init_buffer, term_buffer, base_window, window_counter, next_window, window_size, adapting}
+ *   uint32  ecuyer[2]
+ *   uint32  r_rng[626]  = {mti, mt[624], 0}
+ *   double  scale[4]    = {min, max, range, sigma on the data scale}
+ *   double  offset[n], total_fits[n] (sum of the tree fits on the rescaled scale), then latents[n] (probit only: latent
+ *           response with the offset removed)
+ *   per tree: int32 num_nodes, num_leaves; int32 node[num_nodes][2] in preorder ({var, split} internal, {-1, n_obs} leaf);
+ *             double mu[num_leaves] in DFS order
+ * get_state: call with buf = NULL (or cap too small) to learn the size. */
+#define S4B_STATE_MAGIC 0x53423453u /* "S4BS" */
+typedef struct {
+  uint32_t magic, version;   /* S4B_STATE_MAGIC, 1 */
+  int64_t n;
+  int32_t n_trees, num_unconstrained, is_binary, p;
+  int64_t reserved[2];
+} s4b_state_header;
+int S4B_FN(get_state)(s4b_sampler* s, void* buf, int64_t cap, int64_t* size);
+int S4B_FN(set_state)(s4b_sampler* s, const void* buf, int64_t size);
+
 /* diagnostics used by the parity tests: per-tree-update trace records of 5 int32
  * {type 0 birth 1 death 2 swap 3 change, status 1/0/-1, var, split, num_leaves} */
 int S4B_FN(set_trace)(s4b_sampler* s, int32_t enable);

@@ -215,6 +215,17 @@ class BartFit {
   void serializeTree(int t, std::vector<int32_t>& out, std::vector<double>& mu) const {
     serialize(trees[t], &treeFits[(size_t)t * n], out, mu);
   }
+  // state injection (orc_set_state): rebuild tree t from its preorder serialisation; observation lists by routing the
+  // observations through the rules, per-observation fits from the leaf values (totalFits is set by the caller)
+  void importTree(int t, const int32_t* nodes, int numNodes, const double* mu, int numLeaves) {
+    delete trees[t];
+    trees[t] = newRoot();
+    int pos = 0, leaf = 0;
+    double* fits = &treeFits[(size_t)t * n];
+    importRec(trees[t], nodes, numNodes, mu, numLeaves, pos, leaf, fits);
+    if (pos != numNodes || leaf != numLeaves) throw std::invalid_argument("sampler state: malformed tree");
+  }
+  void refreshRescaledResponse() { if (!cfg.binary) for (size_t i = 0; i < n; ++i) yRescaled[i] = (y[i] - offset[i] - scaleMin) / scaleRange - 0.5; }
   // leaf index (DFS rank) of every training observation for tree t
   void leafAssignment(int t, std::vector<int32_t>& out) const {
     out.assign(n, -1);
@@ -223,6 +234,24 @@ class BartFit {
   }
 
  private:
+  void importRec(Node* nd, const int32_t* nodes, int numNodes, const double* mu, int numLeaves, int& pos, int& leaf, double* fits) {
+    if (pos >= numNodes) throw std::invalid_argument("sampler state: malformed tree");
+    const int32_t v = nodes[2 * pos], s = nodes[2 * pos + 1];
+    ++pos;
+    if (v < 0) {
+      if (leaf >= numLeaves) throw std::invalid_argument("sampler state: malformed tree");
+      const double m = mu[leaf++];
+      for (size_t i : nd->obs) fits[i] = m;
+      return;
+    }
+    if ((size_t)v >= p || s < 0 || s >= numCuts[(size_t)v]) throw std::invalid_argument("sampler state: rule out of range");
+    nd->var = v; nd->split = s;
+    nd->left = new Node; nd->right = new Node;
+    nd->left->parent = nd; nd->right->parent = nd;
+    for (size_t i : nd->obs) (goesRight(nd, i) ? nd->right : nd->left)->obs.push_back(i);
+    importRec(nd->left, nodes, numNodes, mu, numLeaves, pos, leaf, fits);
+    importRec(nd->right, nodes, numNodes, mu, numLeaves, pos, leaf, fits);
+  }
   Node* newRoot() { Node* r = new Node; r->obs.resize(n); for (size_t i = 0; i < n; ++i) r->obs[i] = i; return r; }
 
   void setCutPoints(const double* x, const int* nCuts) {

@@ -433,6 +433,91 @@ int orc_create_stored_bart_sampler(const void* state, int64_t size, int32_t, s4b
     return 0;
   } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
+// sampler state as a byte string (layout: include/stan4bart_amd.h, s4b_get_state); the oracle's own writer / reader
+int orc_get_state(s4b_sampler* s, void* buf, int64_t cap, int64_t* size) {
+  try {
+    if (s->stored) throw std::invalid_argument("this call needs a live sampler");
+    NutsSampler& ns = *s->nuts; BartFit& bf = *s->bart;
+    const int D = ns.D; const size_t n = s->n;
+    Blob o;
+    s4b_state_header hd; std::memset(&hd, 0, sizeof(hd));
+    hd.magic = S4B_STATE_MAGIC; hd.version = 1; hd.n = (int64_t)n; hd.n_trees = bf.cfg.numTrees; hd.num_unconstrained = D; hd.is_binary = s->binary ? 1 : 0; hd.p = (int32_t)bf.p;
+    o.one(hd);
+    o.put(ns.cont_params.data(), (size_t)D); o.put(ns.inv_metric.data(), (size_t)D); o.put(ns.wf_m.data(), (size_t)D); o.put(ns.wf_m2.data(), (size_t)D);
+    const double sc6[6] = {ns.nom_epsilon, ns.sa_mu, ns.sa_counter, ns.sa_s_bar, ns.sa_x_bar, ns.wf_n};
+    o.put(sc6, 6);
+    const double last[7] = {ns.lp_, ns.accept_stat_, ns.epsilon, (double)ns.depth_, (double)ns.n_leapfrog_, ns.divergent_ ? 1.0 : 0.0, ns.energy_};
+    o.put(last, 7);
+    const uint32_t win[8] = {ns.num_warmup_, ns.adapt_init_buffer_, ns.adapt_term_buffer_, ns.adapt_base_window_, ns.adapt_window_counter_, ns.adapt_next_window_,
+                             ns.adapt_window_size_, ns.adapt_flag ? 1u : 0u};
+    o.put(win, 8);
+    const uint32_t ec[2] = {ns.rng.x1, ns.rng.x2};
+    o.put(ec, 2);
+    uint32_t rr[626]; rr[0] = (uint32_t)s->rrng.mti; std::memcpy(rr + 1, s->rrng.mt, 624 * 4); rr[625] = 0u;
+    o.put(rr, 626);
+    const double sc4[4] = {bf.scaleMin, bf.scaleMax, bf.scaleRange, s->binary ? 1.0 : bf.sigma * bf.scaleRange};
+    o.put(sc4, 4);
+    o.put(bf.offset.data(), n); o.put(bf.totalFits.data(), n);
+    if (s->binary) o.put(bf.probitLatents.data(), n);
+    for (int t = 0; t < bf.cfg.numTrees; ++t) {
+      std::vector<int32_t> st; std::vector<double> mu;
+      bf.serializeTree(t, st, mu);
+      o.one<int32_t>((int32_t)(st.size() / 2)); o.one<int32_t>((int32_t)mu.size());
+      o.put(st.data(), st.size()); o.put(mu.data(), mu.size());
+    }
+    *size = (int64_t)o.b.size();
+    if (buf && cap >= *size) std::memcpy(buf, o.b.data(), o.b.size());
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+int orc_set_state(s4b_sampler* s, const void* buf, int64_t size) {
+  try {
+    if (s->stored) throw std::invalid_argument("this call needs a live sampler");
+    NutsSampler& ns = *s->nuts; BartFit& bf = *s->bart;
+    const int D = ns.D; const size_t n = s->n;
+    BlobIn in{(const unsigned char*)buf, (size_t)(size < 0 ? 0 : size), 0};
+    s4b_state_header hd = in.one<s4b_state_header>();
+    if (hd.magic != S4B_STATE_MAGIC || hd.version != 1u) throw std::invalid_argument("not a stan4bart sampler state");
+    if (hd.n != (int64_t)n || hd.n_trees != bf.cfg.numTrees || hd.num_unconstrained != D || (hd.is_binary != 0) != s->binary || hd.p != (int32_t)bf.p)
+      throw std::invalid_argument("sampler state: dimensions do not match this sampler");
+    in.get(ns.cont_params.data(), (size_t)D); in.get(ns.inv_metric.data(), (size_t)D); in.get(ns.wf_m.data(), (size_t)D); in.get(ns.wf_m2.data(), (size_t)D);
+    double sc6[6]; in.get(sc6, 6);
+    ns.nom_epsilon = sc6[0]; ns.sa_mu = sc6[1]; ns.sa_counter = sc6[2]; ns.sa_s_bar = sc6[3]; ns.sa_x_bar = sc6[4]; ns.wf_n = sc6[5];
+    double last[7]; in.get(last, 7);
+    ns.lp_ = last[0]; ns.accept_stat_ = last[1]; ns.epsilon = last[2]; ns.depth_ = (int)last[3]; ns.n_leapfrog_ = (int)last[4]; ns.divergent_ = last[5] != 0.0; ns.energy_ = last[6];
+    uint32_t win[8]; in.get(win, 8);
+    ns.num_warmup_ = win[0]; ns.adapt_init_buffer_ = win[1]; ns.adapt_term_buffer_ = win[2]; ns.adapt_base_window_ = win[3]; ns.adapt_window_counter_ = win[4];
+    ns.adapt_next_window_ = win[5]; ns.adapt_window_size_ = win[6]; ns.adapt_flag = win[7] != 0;
+    uint32_t ec[2]; in.get(ec, 2); ns.rng.x1 = ec[0]; ns.rng.x2 = ec[1];
+    ns.z.q = ns.cont_params;
+    uint32_t rr[626]; in.get(rr, 626);
+    s->rrng.mti = (int)rr[0]; std::memcpy(s->rrng.mt, rr + 1, 624 * 4);
+    double sc4[4]; in.get(sc4, 4);
+    bf.scaleMin = sc4[0]; bf.scaleMax = sc4[1]; bf.scaleRange = sc4[2]; bf.sigma = s->binary ? 1.0 : sc4[3] / sc4[2];
+    in.get(bf.offset.data(), n); in.get(bf.totalFits.data(), n);
+    if (s->binary) in.get(bf.probitLatents.data(), n);
+    bf.refreshRescaledResponse();
+    for (int t = 0; t < bf.cfg.numTrees; ++t) {
+      const int32_t nn = in.one<int32_t>(), nl = in.one<int32_t>();
+      if (nn < 1 || nl < 1 || 2 * nl - 1 != nn) throw std::invalid_argument("sampler state: malformed tree");
+      std::vector<int32_t> st((size_t)nn * 2); std::vector<double> mu((size_t)nl);
+      in.get(st.data(), st.size()); in.get(mu.data(), mu.size());
+      bf.importTree(t, st.data(), nn, mu.data(), nl);
+    }
+    // derived host state: the sample row, the offsets of both blocks, Stan's offset / response (src/init.cpp:828-847)
+    s->row[0] = last[0]; s->row[1] = last[1]; s->row[2] = last[2]; s->row[3] = last[3]; s->row[4] = last[4]; s->row[5] = last[5]; s->row[6] = last[6];
+    s->model->write_array(ns.cont_params, s->row.data() + 7);
+    s->bartOffset = bf.offset;
+    if (s->hasUserOffset && s->offsetType == OFFSET_BART) s->stanOffset = s->userOffset;
+    else {
+      for (size_t j = 0; j < n; ++j) s->stanOffset[j] = s->binary ? bf.totalFits[j] : (bf.totalFits[j] + 0.5) * bf.scaleRange + bf.scaleMin;
+      if (s->hasUserOffset && s->offsetType == OFFSET_DEFAULT) for (size_t j = 0; j < n; ++j) s->stanOffset[j] += s->userOffset[j];
+    }
+    s->model->set_offset(s->stanOffset.data());
+    if (s->binary) { bf.getLatents(s->bartLatents.data()); s->model->set_response(s->bartLatents.data()); }
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
 void orc_free(s4b_sampler* s) { delete s; }
 
 // ---- small extras used only by tests: direct access to the RNG restatements and the model ----

@@ -63,6 +63,7 @@ class StanControl(C.Structure):
 
 
 CALLBACK = C.CFUNCTYPE(C.c_int, C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_int32)
+PROGRESS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32)
 
 
 class CommonControl(C.Structure):
@@ -251,14 +252,39 @@ class Sampler:
 
     # ------------------------------------------------------------------ plumbing
     def _bind(self):
-        for name in ("create", "run", "disengage_adaptation", "print_initial_summary", "get_parametric_mean",
-                     "get_bart_data_range", "get_r_rng_state", "set_r_rng_state", "get_dims", "get_stan_par_names",
-                     "get_trees", "set_trace", "get_trace", "get_leaf_assignment", "get_counters", "profile_sweep", "predict_bart",
-                     "export_bart_state", "create_stored_bart_sampler", "profile_leapfrog", "get_kept_trees"):
-            getattr(self._lib, self._pfx + name).restype = C.c_int
+        """restype + argtypes of every entry point of include/stan4bart_amd.h (64-bit counts travel as c_int64)."""
+        vp, i32, i64, dp, ip, up = C.c_void_p, C.c_int32, C.c_int64, c_double_p, c_int32_p, c_uint32_p
+        sig = {
+            "create": [C.POINTER(BartControl), C.POINTER(BartData), C.POINTER(StanData), C.POINTER(StanControl),
+                       C.POINTER(CommonControl), up, C.POINTER(vp)],
+            "run": [vp, i32, i32, i32, C.POINTER(Results)],
+            "disengage_adaptation": [vp], "print_initial_summary": [vp],
+            "get_parametric_mean": [vp, dp], "get_bart_data_range": [vp, dp],
+            "get_r_rng_state": [vp, up], "set_r_rng_state": [vp, up],
+            "get_dims": [vp, C.POINTER(i64)], "get_stan_par_names": [vp, C.c_char_p, C.c_size_t],
+            "get_trees": [vp, i64, ip, ip, ip, ip, dp, C.POINTER(i64)],
+            "get_kept_trees": [vp, i64, i64, ip, ip, ip, ip, ip, dp, C.POINTER(i64)],
+            "get_kept_trees_indexed": [vp, ip, i64, ip, i64, i64, ip, ip, ip, ip, ip, dp, C.POINTER(i64)],
+            "export_bart_state": [vp, vp, i64, C.POINTER(i64)],
+            "create_stored_bart_sampler": [vp, i64, i32, C.POINTER(vp)],
+            "predict_bart": [vp, dp, i64, dp, C.POINTER(i64)],
+            "predict_bart_offset": [vp, dp, i64, dp, dp, C.POINTER(i64)],
+            "get_state": [vp, vp, i64, C.POINTER(i64)], "set_state": [vp, vp, i64],
+            "set_trace": [vp, i32], "get_trace": [vp, i64, ip, C.POINTER(i64)],
+            "get_leaf_assignment": [vp, i32, ip], "get_counters": [vp, C.POINTER(i64)],
+            "profile_sweep": [vp, i32, dp], "profile_leapfrog": [vp, i32, dp],
+            "set_progress": [vp, PROGRESS, vp],
+        }
+        for name, argtypes in sig.items():
+            fn = getattr(self._lib, self._pfx + name, None)
+            if fn is None:          # optional entry points (the oracle exports the subset the tests drive)
+                continue
+            fn.restype = C.c_int
+            fn.argtypes = argtypes
         getattr(self._lib, self._pfx + "last_error").restype = C.c_char_p
+        getattr(self._lib, self._pfx + "last_error").argtypes = []
         getattr(self._lib, self._pfx + "free").restype = None
-        getattr(self._lib, self._pfx + "free").argtypes = [C.c_void_p]
+        getattr(self._lib, self._pfx + "free").argtypes = [vp]
 
     def _f(self, name):
         return getattr(self._lib, self._pfx + name)
@@ -381,6 +407,19 @@ class Sampler:
         out = (C.c_double * 8)()
         self._check(self._f("profile_leapfrog")(self._h, n_evals, out))
         return dict(kernels_us=out[0], with_fetch_us=out[1], launches=out[2], n=int(out[3]), algorithmic_bytes=out[4])
+
+    def get_state(self) -> bytes:
+        """``s4b_get_state``: the whole sampler state (NUTS + adaptation, trees, fits, offsets, both generators)."""
+        size = C.c_int64()
+        self._check(self._f("get_state")(self._h, None, 0, C.byref(size)))
+        buf = C.create_string_buffer(size.value)
+        self._check(self._f("get_state")(self._h, buf, size.value, C.byref(size)))
+        return buf.raw[: size.value]
+
+    def set_state(self, state: bytes):
+        """``s4b_set_state``: resume from / be teacher-forced to a state produced by ``get_state`` of either implementation."""
+        buf = C.create_string_buffer(state, len(state))
+        self._check(self._f("set_state")(self._h, buf, len(state)))
 
     def export_bart_state(self) -> bytes:
         """``stan4bart_exportBARTState``: the kept trees + cut points + scales as one byte string."""

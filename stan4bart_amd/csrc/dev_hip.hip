@@ -854,7 +854,8 @@ __global__ __launch_bounds__(BLOCK) void k_apply(BartArrays a, int t) {
 
 // ------------------------------------------------------------------------------------------------
 // tree initialisation: full traversal for every tree, residual from scratch
-__global__ __launch_bounds__(BLOCK) void k_assign_leaves(BartArrays a) {
+// withResidual = 0 (set_state): only the leaf planes, the residual is given
+__global__ __launch_bounds__(BLOCK) void k_assign_leaves(BartArrays a, int withResidual) {
   const ScaleState sc = *a.scale;
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK) {
     double r = a.binary ? a.lat[i] : (a.y[i] - a.off[i] - sc.min) / sc.range - 0.5;
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(BLOCK) void k_assign_leaves(BartArrays a) {
       a.leaf[(size_t)t * a.npad + (size_t)i] = (uint16_t)nd;
       r -= a.mu[o + nd];
     }
-    a.R[i] = r;
+    if (withResidual) a.R[i] = r;
   }
 }
 
@@ -1538,7 +1539,28 @@ class DevHip {
   }
 
   // ---- trees
-  void assign_leaves_and_residual() { hipLaunchKernelGGL(k_assign_leaves, dim3(gridN_), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+  void assign_leaves_and_residual() { hipLaunchKernelGGL(k_assign_leaves, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, 1); ++launches_; }
+  void assign_leaves_only() { hipLaunchKernelGGL(k_assign_leaves, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, 0); ++launches_; }
+  // ---- state injection / extraction (s4b_set_state / s4b_get_state)
+  double* obs_array(int which) {
+    switch (which) {
+      case OBS_R: return a_.R;
+      case OBS_OFF: return a_.off;
+      case OBS_LAT: if (!a_.lat) throw std::invalid_argument("latents exist only for binary responses"); return a_.lat;
+      case OBS_Y: return const_cast<double*>(a_.y);
+    }
+    throw std::invalid_argument("unknown observation array");
+  }
+  void download_obs(int which, double* out) { download(out, obs_array(which), (size_t)n_); sync(); }
+  void upload_obs(int which, const double* in) {
+    if (which == OBS_Y) throw std::invalid_argument("the response is fixed at creation");
+    upload(obs_array(which), in, (size_t)n_); sync();
+  }
+  void upload_counts(const int32_t* cnt) { upload(a_.cnt, cnt, (size_t)T_ * nc_); sync(); }
+  void set_scale(double mn, double mx, double range, double sigmaData) {
+    ScaleState sc; sc.min = mn; sc.max = mx; sc.range = range; sc.min0 = mn; sc.range0 = range; sc.shiftPerTree = 0.0; sc.sigmaData = sigmaData; sc.sigma = sigmaData / range;
+    upload(a_.scale, &sc, 1); sync();
+  }
   // One sweep = 2 T + 2 launches with arguments that never change (per-tree state is reached through pointers), so
   // it is captured once into a hipGraph and replayed: the host then costs one call per sweep instead of ~4 us per launch.
   void sweep(int thin) {

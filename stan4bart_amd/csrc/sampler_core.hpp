@@ -28,6 +28,7 @@
 namespace s4b {
 
 enum { OFFSET_DEFAULT = 0, OFFSET_FIXEF, OFFSET_RANEF, OFFSET_BART, OFFSET_PARAMETRIC };
+enum { OBS_R = 0, OBS_OFF, OBS_LAT, OBS_Y };   // observation-length device arrays addressable through download_obs / upload_obs
 
 // a node of a kept tree (predict): children are slot ids relative to the tree's first record
 struct PackedNode { int16_t var; uint16_t cut; int16_t left, right; double mu; int32_t n; int32_t pad; };   // n: observations in the node
@@ -362,6 +363,131 @@ class SamplerCore {
     dev_.predict_stored(xb.data(), nT, keptNodes_.data(), keptNodes_.size(), keptTreeStart_.data(), S, T_, keptScale_.data(), binary_ ? 1 : 0, out);
     return S;
   }
+  // ---- sampler state as a byte string (layout: include/stan4bart_amd.h, s4b_get_state)
+  int64_t get_state(void* buf, int64_t cap) {
+    live();
+    const int D = model_->sp.D;
+    HostTrees h; download_trees(h);
+    std::vector<std::vector<int32_t>> nodes((size_t)T_); std::vector<std::vector<double>> leafMu((size_t)T_);
+    size_t treeBytes = 0;
+    for (int t = 0; t < T_; ++t) {
+      TreeView tv = h.view(t, nc_);
+      int nd, k; Walker<TreeView> w(tv, 0);
+      while (w.next(nd, k)) {
+        if (k == 2) continue;
+        if (k == 1) { nodes[(size_t)t].push_back(tv.var.get(nd)); nodes[(size_t)t].push_back((int32_t)tv.cut.get(nd)); }
+        else { nodes[(size_t)t].push_back(-1); nodes[(size_t)t].push_back(h.cnt[(size_t)t * nc_ + nd]); leafMu[(size_t)t].push_back(h.mu[(size_t)t * nc_ + nd]); }
+      }
+      treeBytes += 8 + nodes[(size_t)t].size() * 4 + leafMu[(size_t)t].size() * 8;
+    }
+    const size_t need = sizeof(s4b_state_header) + (size_t)(4 * D + 6 + 7) * 8 + (8 + 2 + 626) * 4 + 4 * 8 + (size_t)(binary_ ? 3 : 2) * n_ * 8 + treeBytes;
+    if (!buf || cap < (int64_t)need) return (int64_t)need;
+    unsigned char* o = (unsigned char*)buf;
+    auto put = [&](const void* src, size_t k) { if (k) std::memcpy(o, src, k); o += k; };
+    s4b_state_header hd; std::memset(&hd, 0, sizeof(hd));
+    hd.magic = S4B_STATE_MAGIC; hd.version = 1; hd.n = (int64_t)n_; hd.n_trees = T_; hd.num_unconstrained = D; hd.is_binary = binary_ ? 1 : 0; hd.p = P_;
+    put(&hd, sizeof(hd));
+    Nuts::State ns; nuts_->get_state(ns);
+    put(ns.q.data(), (size_t)D * 8); put(ns.inv_metric.data(), (size_t)D * 8); put(ns.wm.data(), (size_t)D * 8); put(ns.wm2.data(), (size_t)D * 8);
+    const double sc6[6] = {ns.stepsize, ns.mu, ns.counter, ns.s_bar, ns.x_bar, ns.wn};
+    put(sc6, sizeof(sc6)); put(ns.last, sizeof(ns.last));
+    uint32_t win[8]; for (int i = 0; i < 7; ++i) win[i] = ns.window[i]; win[7] = (uint32_t)ns.adapting;
+    put(win, sizeof(win)); put(ns.rng, sizeof(ns.rng));
+    uint32_t rr[626]; get_rng(rr); rr[625] = 0u;
+    put(rr, sizeof(rr));
+    ScaleState scl; dev_.get_scale(scl);
+    const double sc4[4] = {scl.min, scl.max, scl.range, scl.sigmaData};
+    put(sc4, sizeof(sc4));
+    std::vector<double> off(n_), R(n_), aux(n_);
+    dev_.download_obs(OBS_OFF, off.data()); dev_.download_obs(OBS_R, R.data());
+    dev_.download_obs(binary_ ? OBS_LAT : OBS_Y, aux.data());
+    put(off.data(), n_ * 8);
+    if (binary_) { for (size_t i = 0; i < n_; ++i) R[i] = aux[i] - R[i]; }
+    else for (size_t i = 0; i < n_; ++i) R[i] = ((aux[i] - off[i] - scl.min) / scl.range - 0.5) - R[i];
+    put(R.data(), n_ * 8);
+    if (binary_) put(aux.data(), n_ * 8);
+    for (int t = 0; t < T_; ++t) {
+      const int32_t cnt[2] = {(int32_t)(nodes[(size_t)t].size() / 2), (int32_t)leafMu[(size_t)t].size()};
+      put(cnt, sizeof(cnt)); put(nodes[(size_t)t].data(), nodes[(size_t)t].size() * 4); put(leafMu[(size_t)t].data(), leafMu[(size_t)t].size() * 8);
+    }
+    return (int64_t)need;
+  }
+  void set_state(const void* buf, int64_t size) {
+    live();
+    const int D = model_->sp.D;
+    Reader r{(const unsigned char*)buf, (size_t)(size < 0 ? 0 : size), 0};
+    r.what = "sampler state: truncated";
+    s4b_state_header hd;
+    if (!buf) throw std::invalid_argument("set_state: NULL buffer");
+    r.get(&hd, sizeof(hd));
+    if (hd.magic != S4B_STATE_MAGIC) throw std::invalid_argument("not a stan4bart sampler state");
+    if (hd.version != 1u) throw std::invalid_argument("sampler state: unknown version");
+    if (hd.n != (int64_t)n_ || hd.n_trees != T_ || hd.num_unconstrained != D || (hd.is_binary != 0) != binary_ || hd.p != P_)
+      throw std::invalid_argument("sampler state: dimensions do not match this sampler");
+    Nuts::State ns;
+    ns.q.resize((size_t)D); ns.inv_metric.resize((size_t)D); ns.wm.resize((size_t)D); ns.wm2.resize((size_t)D);
+    r.get(ns.q.data(), (size_t)D * 8); r.get(ns.inv_metric.data(), (size_t)D * 8); r.get(ns.wm.data(), (size_t)D * 8); r.get(ns.wm2.data(), (size_t)D * 8);
+    double sc6[6]; r.get(sc6, sizeof(sc6)); r.get(ns.last, sizeof(ns.last));
+    ns.stepsize = sc6[0]; ns.mu = sc6[1]; ns.counter = sc6[2]; ns.s_bar = sc6[3]; ns.x_bar = sc6[4]; ns.wn = sc6[5];
+    uint32_t win[8]; r.get(win, sizeof(win)); r.get(ns.rng, sizeof(ns.rng));
+    for (int i = 0; i < 7; ++i) ns.window[i] = win[i];
+    ns.adapting = (int32_t)win[7];
+    uint32_t rr[626]; r.get(rr, sizeof(rr));
+    if (rr[0] > 624u) throw std::invalid_argument("sampler state: generator position out of range");
+    double sc4[4]; r.get(sc4, sizeof(sc4));
+    if (!(sc4[2] > 0.0) || !(sc4[3] > 0.0)) throw std::invalid_argument("sampler state: response range and sigma must be positive");
+    std::vector<double> off(n_), fits(n_), lat;
+    r.get(off.data(), n_ * 8); r.get(fits.data(), n_ * 8);
+    if (binary_) { lat.resize(n_); r.get(lat.data(), n_ * 8); }
+    // trees: preorder -> node slots in preorder (slot ids carry no meaning: every move addresses nodes by traversal order)
+    HostTrees h; h.alloc(T_, nc_);
+    for (int t = 0; t < T_; ++t) {
+      int32_t cnt[2]; r.get(cnt, sizeof(cnt));
+      if (cnt[0] < 1 || cnt[0] > nc_ || cnt[1] < 1 || 2 * cnt[1] - 1 != cnt[0]) throw std::invalid_argument("sampler state: tree does not fit node_capacity");
+      std::vector<int32_t> nd((size_t)cnt[0] * 2); std::vector<double> mu((size_t)cnt[1]);
+      r.get(nd.data(), nd.size() * 4); r.get(mu.data(), mu.size() * 8);
+      const size_t o = (size_t)t * nc_;
+      int leaf = 0; std::vector<int> open;   // parents still waiting for their right child
+      for (int i = 0; i < cnt[0]; ++i) {
+        int par = -1;
+        if (i > 0) {
+          if (open.empty()) throw std::invalid_argument("sampler state: malformed tree");
+          par = open.back();
+          if (h.left[o + (size_t)par] < 0) h.left[o + (size_t)par] = (int16_t)i; else { h.right[o + (size_t)par] = (int16_t)i; open.pop_back(); }
+        }
+        h.parent[o + (size_t)i] = (int16_t)par;
+        const int32_t v = nd[(size_t)2 * i], s2 = nd[(size_t)2 * i + 1];
+        if (v >= 0) {
+          if (v >= P_ || s2 < 0 || s2 >= numCuts_[(size_t)v]) throw std::invalid_argument("sampler state: rule out of range");
+          h.var[o + (size_t)i] = (int16_t)v; h.cut[o + (size_t)i] = (uint16_t)s2; open.push_back(i);
+        } else {
+          if (leaf >= cnt[1]) throw std::invalid_argument("sampler state: malformed tree");
+          h.var[o + (size_t)i] = NODE_LEAF; h.mu[o + (size_t)i] = mu[(size_t)leaf++]; h.cnt[o + (size_t)i] = s2;
+        }
+      }
+      if (!open.empty() || leaf != cnt[1]) throw std::invalid_argument("sampler state: malformed tree");
+      h.hwm[(size_t)t] = cnt[0];
+    }
+    // ---- commit
+    nuts_->set_state(ns);
+    nuts_->current_row(row_.data());
+    set_rng(rr);
+    sigma_ = sc4[3];
+    dev_.set_scale(sc4[0], sc4[1], sc4[2], sc4[3]);
+    dev_.upload_obs(OBS_OFF, off.data());
+    if (binary_) { dev_.upload_obs(OBS_LAT, lat.data()); for (size_t i = 0; i < n_; ++i) fits[i] = lat[i] - fits[i]; }
+    else {
+      std::vector<double> y(n_); dev_.download_obs(OBS_Y, y.data());
+      for (size_t i = 0; i < n_; ++i) fits[i] = ((y[i] - off[i] - sc4[0]) / sc4[2] - 0.5) - fits[i];
+    }
+    dev_.upload_obs(OBS_R, fits.data());
+    dev_.upload_trees(h.var.data(), h.cut.data(), h.left.data(), h.right.data(), h.parent.data(), h.mu.data(), h.hwm.data());
+    dev_.upload_counts(h.cnt.data());
+    dev_.assign_leaves_only();
+    dev_.stan_inputs(stan_mode(), false, cX_.data(), cZ_.data(), &s0_, nullptr);
+    check_device();
+  }
+
   void set_trace(bool on) { live(); dev_.set_trace(on); }
   int64_t get_trace(int64_t cap, int32_t* out) { live(); return dev_.get_trace(cap, out); }
   void leaf_assignment(int t, int32_t* out) {
@@ -396,8 +522,8 @@ class SamplerCore {
  private:
   static constexpr uint32_t STATE_MAGIC = 0x54423453u;   // "S4BT"
   struct Reader {
-    const unsigned char* p; size_t n, pos;
-    void get(void* dst, size_t k) { if (pos + k > n) throw std::invalid_argument("exported BART state: truncated"); if (k) std::memcpy(dst, p + pos, k); pos += k; }
+    const unsigned char* p; size_t n, pos; const char* what = "exported BART state: truncated";
+    void get(void* dst, size_t k) { if (k > n || pos > n - k) throw std::invalid_argument(what); if (k) std::memcpy(dst, p + pos, k); pos += k; }
     uint32_t u32() { uint32_t v; get(&v, 4); return v; }
     uint64_t u64() { uint64_t v; get(&v, 8); return v; }
   };

@@ -427,6 +427,8 @@ class StanRng {
     return x2_ < x1_ ? x1_ - x2_ : x1_ - x2_ + 2147483562u;
   }
   double u01() { return (double)(raw() - 1u) / 2147483562.0; }
+  void get_state(uint32_t out[2]) const { out[0] = x1_; out[1] = x2_; }
+  void set_state(const uint32_t in[2]) { x1_ = in[0]; x2_ = in[1]; }
   double uniform(double a, double b) { for (;;) { double r = u01() * (b - a) + a; if (r < b) return r; } }
   double normal() {
     for (;;) {
@@ -527,6 +529,45 @@ class Nuts {
     model_.write_array(cont_, row + 7);
   }
   void disengage() { adapting_ = false; nom_eps_ = std::exp(x_bar_); }
+
+  // Everything that carries over from one transition to the next (s4b_get_state / s4b_set_state: checkpoint / resume and
+  // the teacher-forced parity tests).  Momentum, gradient and potential are recomputed at the start of a transition
+  // (base_nuts.hpp:85-91), so they are not part of the state.
+  struct State {
+    V q, inv_metric, wm, wm2;
+    double stepsize = 0, mu = 0, counter = 0, s_bar = 0, x_bar = 0, wn = 0;
+    int32_t adapting = 1;
+    uint32_t window[7] = {0, 0, 0, 0, 0, 0, 0};   // num_warmup, init_buffer, term_buffer, base_window, window_counter, next_window, window_size
+    uint32_t rng[2] = {1, 1};
+    double last[7] = {0, 0, 0, 0, 0, 0, 0};       // sampler columns of the last emitted row
+  };
+  void get_state(State& s) const {
+    s.q = cont_; s.inv_metric = inv_metric_; s.wm = wm_; s.wm2 = wm2_;
+    s.stepsize = nom_eps_; s.mu = mu_; s.counter = counter_; s.s_bar = s_bar_; s.x_bar = x_bar_; s.wn = wn_;
+    s.adapting = adapting_ ? 1 : 0;
+    const uint32_t w[7] = {num_warmup_, init_buffer_, term_buffer_, base_window_, window_counter_, next_window_, window_size_};
+    for (int i = 0; i < 7; ++i) s.window[i] = w[i];
+    rng_.get_state(s.rng);
+    const double l[7] = {lp_, accept_, eps_, (double)depth_, (double)n_leapfrog_, divergent_ ? 1.0 : 0.0, energy_};
+    for (int i = 0; i < 7; ++i) s.last[i] = l[i];
+  }
+  void set_state(const State& s) {
+    if ((int)s.q.size() != D_ || (int)s.inv_metric.size() != D_ || (int)s.wm.size() != D_ || (int)s.wm2.size() != D_)
+      throw std::invalid_argument("sampler state: wrong number of unconstrained parameters");
+    cont_ = s.q; z_.q = s.q; inv_metric_ = s.inv_metric; wm_ = s.wm; wm2_ = s.wm2;
+    nom_eps_ = s.stepsize; mu_ = s.mu; counter_ = s.counter; s_bar_ = s.s_bar; x_bar_ = s.x_bar; wn_ = s.wn;
+    adapting_ = s.adapting != 0;
+    num_warmup_ = s.window[0]; init_buffer_ = s.window[1]; term_buffer_ = s.window[2]; base_window_ = s.window[3];
+    window_counter_ = s.window[4]; next_window_ = s.window[5]; window_size_ = s.window[6];
+    rng_.set_state(s.rng);
+    lp_ = s.last[0]; accept_ = s.last[1]; eps_ = s.last[2]; depth_ = (int)s.last[3]; n_leapfrog_ = (int)s.last[4];
+    divergent_ = s.last[5] != 0.0; energy_ = s.last[6];
+  }
+  // the sample row of the current point (sampler columns as last emitted)
+  void current_row(double* row) {
+    row[0] = lp_; row[1] = accept_; row[2] = eps_; row[3] = depth_; row[4] = n_leapfrog_; row[5] = divergent_ ? 1 : 0; row[6] = energy_;
+    model_.write_array(cont_, row + 7);
+  }
 
  private:
   HostModel& model_; int D_, skip_;

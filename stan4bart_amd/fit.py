@@ -73,23 +73,56 @@ def make_z_csr(groups: Sequence[GroupTerm], n: int):
 
 
 def init_fit(y, Xc, groups, n, is_binary):
-    """bart_offset_init / sigma_init from the lm fallback of reference R/stan4bart.R:160-186
-    (``subbars``: grouping factors enter as fixed dummies).  lme4 is not available here."""
-    cols = [np.ones(n)]
-    if Xc.shape[1]:
-        cols += [Xc[:, j] for j in range(Xc.shape[1])]
+    """bart_offset_init / sigma_init from the lm / glm fallback of reference R/stan4bart.R:156-178 (``subbars``: the grouping
+    factors enter as fixed dummies; lme4 is not available here).  The design [1 | Xc | level dummies] is never formed
+    densely: it has 1 + K dense columns and one non-zero per grouping factor and row, so the normal equations are
+    assembled from a sparse matrix (m x m with m = 1 + K + sum(levels - 1)) and the rank comes from the small Gram matrix.
+    Gaussian: least squares, sigma = sqrt(RSS / (n - rank)) (``sigma(lm)``).  Binomial: probit IRLS (``glm(family =
+    binomial("probit"))``); the reference takes ``fitted(init_fit, type = "link")`` (R/stan4bart.R:172), and ``fitted()``
+    ignores ``type`` for a glm, so what it hands to BART is the fitted mean Phi(eta) — reproduced here."""
+    from scipy import sparse
+    from scipy.special import ndtr
+    y = np.asarray(y, dtype=np.float64)
+    K = Xc.shape[1]
+    blocks = [sparse.csr_matrix(np.column_stack([np.ones(n), Xc]) if K else np.ones((n, 1)))]
     for g in groups:
         lev = np.asarray(g.levels, dtype=np.int64)
-        for k in range(2, g.l + 1):
-            cols.append((lev == k).astype(float))
-    A = np.stack(cols, axis=1)
-    if is_binary:
-        return None, 1.0
-    coef, *_ = np.linalg.lstsq(A, y, rcond=None)
-    fitted = A @ coef
-    rank = np.linalg.matrix_rank(A)
-    sigma = float(np.sqrt(np.sum((y - fitted) ** 2) / max(1, n - rank)))
-    return fitted, sigma
+        if g.l < 2:
+            continue
+        keep = lev >= 2
+        blocks.append(sparse.csr_matrix((np.ones(int(keep.sum())), (np.flatnonzero(keep), lev[keep] - 2)), shape=(n, g.l - 1)))
+    A = sparse.hstack(blocks, format="csr")
+
+    def wls(wt, z):
+        Aw = A.multiply(wt[:, None]).tocsr() if wt is not None else A
+        G = (Aw.T @ A).toarray()
+        rhs = Aw.T @ z
+        coef, _, rank, _ = np.linalg.lstsq(G, rhs, rcond=1e-11)
+        return coef, int(rank)
+
+    if not is_binary:
+        coef, rank = wls(None, y)
+        fitted = A @ coef
+        sigma = float(np.sqrt(np.sum((y - fitted) ** 2) / max(1, n - rank)))
+        return fitted, sigma
+    # probit IRLS, glm.fit's scheme: mustart = (y + 0.5) / 2, eta = qnorm(mu), deviance convergence (epsilon = 1e-8, maxit 25)
+    from scipy.special import ndtri
+    mu = (y + 0.5) / 2.0
+    eta = ndtri(mu)
+    dev_old = np.inf
+    for _ in range(25):
+        dmu = np.exp(-0.5 * eta * eta) / np.sqrt(2.0 * np.pi)
+        var = mu * (1.0 - mu)
+        wt = dmu * dmu / var
+        z = eta + (y - mu) / dmu
+        coef, _ = wls(wt, z)
+        eta = A @ coef
+        mu = np.clip(ndtr(eta), 1e-15, 1.0 - 1e-15)
+        dev = -2.0 * float(np.sum(np.where(y > 0, np.log(mu), np.log1p(-mu))))
+        if abs(dev - dev_old) / (abs(dev) + 0.1) < 1e-8:
+            break
+        dev_old = dev
+    return mu, 1.0
 
 
 def make_sampler_args(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_test=None, family: str = "gaussian",

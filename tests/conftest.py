@@ -62,6 +62,171 @@ def friedman_case(n=100, ranef=True, slopes=False, p=10, T=11, warmup=7, iter=13
     return args, d
 
 
+def binary_case(n=200, T=11, warmup=7, iter=13, ranef=True, n_test=0, **kw):
+    """Friedman data with a binary response (probit link), same formula as friedman_case."""
+    from stan4bart_amd import GroupTerm, generate_friedman_data, make_sampler_args
+    d = generate_friedman_data(n, ranef=ranef, causal=True, binary=True)
+    x = d["x"]
+    xb = x[:, [0, 1, 2, 4, 5, 6, 7, 8, 9]]
+    groups = [GroupTerm(d["g1"], None), GroupTerm(d["g2"], None)] if ranef else []
+    return make_sampler_args(d["y"], xb, X=np.column_stack([x[:, 3], d["z"]]), groups=groups, family="binomial", iter=iter,
+                             warmup=warmup, x_test=xb[:n_test].copy() if n_test else None, bart_args={"n.trees": T}, **kw)
+
+
+def ihdp_case(warmup=7, iter=13, T=50, seed=20260102):
+    """BASELINE config 4 at its shape: the 747 x 25 IHDP covariates (6 continuous, 19 binary; tests/golden/ihdp_covariates.npz,
+    made by tools/make_ihdp_fixture.py from the reference's ihdp/sim.data.gz following ihdp/data.R:1-22), treatment z, one
+    26-level grouping factor (mother's age), formula of the reference's IHDP method (ihdp/methods/stan4bart.R:5):
+    y ~ bart(x, z) + (1 + z | g1), treatment = z (test sample = counterfactual rows), binary outcome / probit link.
+    The reference's simulation (ihdp/sim.R:55-85, response surface C) yields a continuous outcome; the binary variant
+    BASELINE.json names is defined here as y = 1[y_c > median(y_c)] with y_c = main effects + sparse pairwise interactions +
+    tau z + group intercept / slope + noise on the standardised covariates."""
+    from stan4bart_amd import GroupTerm, make_sampler_args
+    f = np.load(os.path.join(ROOT, "tests", "golden", "ihdp_covariates.npz"))
+    x, z, g1 = f["x"], f["z"], f["g1"]
+    n, p = x.shape
+    assert (n, p) == (747, 25) and g1.max() == 26
+    xz = x.copy()
+    xz[:, :6] = (x[:, :6] - x[:, :6].mean(axis=0)) / x[:, :6].std(axis=0, ddof=1)
+    g = np.random.default_rng(seed)
+    beta = g.choice([0.0, 1.0, 2.0], size=p + 1, p=[0.6, 0.3, 0.1])
+    pairs = [(i, j) for i in range(p) for j in range(i + 1, p)]
+    sel = g.choice(len(pairs), size=20, replace=False)
+    mu = beta[0] + xz @ beta[1:]
+    for k in sel:
+        i, j = pairs[k]
+        mu = mu + g.choice([0.5, 1.0]) * xz[:, i] * xz[:, j]
+    b = g.standard_normal((26, 2)) @ np.linalg.cholesky(np.array([[1.0, 0.2], [0.2, 0.5]])).T
+    yc = mu + 4.0 * z + b[g1 - 1, 0] + b[g1 - 1, 1] * z + g.standard_normal(n)
+    y = (yc > np.median(yc)).astype(np.float64)
+    xb = np.column_stack([x, z])
+    xt = np.column_stack([x, 1.0 - z])
+    return make_sampler_args(y, xb, X=None, groups=[GroupTerm(g1, z, "g1")], family="binomial", iter=iter, warmup=warmup,
+                             x_test=xt, bart_args={"n.trees": T})
+
+
+def c5_case(n, P=100, T=400, n_groups=200, warmup=2, iter=4, n_test=0, seed=99, **kw):
+    """BASELINE config 5 shape: P BART predictors, T trees, (1 + X4 | g.1) with n_groups groups (q = 2 n_groups).  The
+    predictors come from numpy's generator column by column (the R-compatible stream would take minutes at n = 1e7; the
+    path does not care which generator made x) and are built straight in the layout the C boundary takes, so that the
+    n = 1e7 case needs one 8 GB matrix on the host and no second copy."""
+    from stan4bart_amd import GroupTerm, make_sampler_args
+    g = np.random.default_rng(seed)
+    xb = np.empty((n, P), order="F")
+    for j in range(P):
+        xb[:, j] = g.random(n)
+    x4 = g.random(n)
+    z = (g.random(n) < 0.2).astype(np.float64)
+    g1 = g.integers(1, n_groups + 1, size=n)
+    b = g.standard_normal((n_groups, 2)) @ np.linalg.cholesky(np.array([[2.25, 0.2], [0.2, 1.0]])).T
+    y = (10.0 * np.sin(np.pi * xb[:, 0] * xb[:, 1]) + 20.0 * (xb[:, 2] - 0.5) ** 2 + 5.0 * xb[:, 3] + 10.0 * x4 + 5.0 * z
+         + b[g1 - 1, 0] + b[g1 - 1, 1] * x4 + g.standard_normal(n))
+    x_test = xb[:n_test].copy() if n_test else None
+    return make_sampler_args(y, xb, X=np.column_stack([x4, z]), groups=[GroupTerm(g1, x4, "g.1")], iter=iter, warmup=warmup,
+                             x_test=x_test, bart_args={"n.trees": T}, **kw), xb
+
+
+def make_sampler(lib, prefix, args, seed=12345):
+    """One seeded sampler (chain set-up of stan4bart_fit_worker, reference R/stan4bart_fit.R:33-47)."""
+    import copy
+    from stan4bart_amd import RRng
+    from stan4bart_amd.abi import Sampler
+    args = copy.copy(args)
+    rng = RRng(seed)
+    args.seed = int(rng.sample_int(2147483647, 1)[0])
+    return Sampler(lib, prefix, args, rng.state)
+
+
+class StateView:
+    """Parsed view of a sampler-state blob (layout: include/stan4bart_amd.h, s4b_get_state) for the tests: field access and
+    patching (forced step sizes) without going through either implementation."""
+
+    def __init__(self, blob: bytes):
+        self.b = bytearray(blob)
+        magic, version, n, T, D, binary, p = np.frombuffer(self.b, dtype=np.uint32, count=2).tolist() + \
+            [int(np.frombuffer(self.b, dtype=np.int64, count=1, offset=8)[0])] + np.frombuffer(self.b, dtype=np.int32, count=4, offset=16).tolist()
+        assert magic == 0x53423453 and version == 1
+        self.n, self.T, self.D, self.binary, self.p = n, T, D, binary, p
+        o = 48
+        self.off = {}
+        for name, cnt in (("q", D), ("inv_metric", D), ("wm", D), ("wm2", D), ("nuts", 6), ("last", 7)):
+            self.off[name] = (o, cnt, np.float64); o += 8 * cnt
+        for name, cnt in (("win", 8), ("ecuyer", 2), ("r_rng", 626)):
+            self.off[name] = (o, cnt, np.uint32); o += 4 * cnt
+        for name, cnt in (("scale", 4), ("offset", n), ("total_fits", n)) + ((("latents", n),) if binary else ()):
+            self.off[name] = (o, cnt, np.float64); o += 8 * cnt
+        self.trees = []
+        for _ in range(T):
+            nn, nl = np.frombuffer(self.b, dtype=np.int32, count=2, offset=o).tolist(); o += 8
+            nodes = np.frombuffer(self.b, dtype=np.int32, count=2 * nn, offset=o).reshape(nn, 2).copy(); o += 8 * nn
+            mu = np.frombuffer(self.b, dtype=np.float64, count=nl, offset=o).copy(); o += 8 * nl
+            self.trees.append((nodes, mu))
+        assert o == len(self.b)
+
+    def get(self, name):
+        o, cnt, dt = self.off[name]
+        return np.frombuffer(self.b, dtype=dt, count=cnt, offset=o).copy()
+
+    def set(self, name, values):
+        o, cnt, dt = self.off[name]
+        v = np.ascontiguousarray(values, dtype=dt)
+        assert v.shape == (cnt,)
+        self.b[o:o + v.nbytes] = v.tobytes()
+
+    def bytes(self):
+        return bytes(self.b)
+
+
+def assert_state_parity(a: "StateView", b: "StateView", rtol=1e-6, atol=1e-9):
+    """Two state blobs describe the same chain state: integers / generator states / tree structure bit-exact, floats rtol."""
+    for k in ("win", "ecuyer", "r_rng"):
+        assert np.array_equal(a.get(k), b.get(k)), k
+    for k in ("q", "inv_metric", "wm", "wm2", "nuts", "last", "scale", "offset", "total_fits") + (("latents",) if a.binary else ()):
+        np.testing.assert_allclose(a.get(k), b.get(k), rtol=rtol, atol=atol, err_msg=k)
+    for (na, ma), (nb, mb) in zip(a.trees, b.trees):
+        assert np.array_equal(na, nb)
+        np.testing.assert_allclose(ma, mb, rtol=rtol, atol=atol)
+
+
+def teacher_forced(oracle_lib, lib, prefix, args, seed=12345, patch=None, compare_states=True, rtol=1e-6, atol=1e-9):
+    """Teacher-forced per-iteration parity (SURVEY.md §7 "Hard parts"): the oracle runs the whole chain; before EVERY Gibbs
+    iteration its state is injected into the product sampler (`prefix`), both advance one iteration and are compared:
+    bit-exact on the tree-move trace, R generator state, NUTS treedepth / n_leapfrog / divergent, rtol on the rest.
+    `patch(it, StateView)` may edit the state both sides start iteration `it` from (returns True if it did).
+    Returns the oracle's rows [num_pars x iter] and the list of iterations where a metric window ended."""
+    so, sp = make_sampler(oracle_lib, "orc_", args, seed), make_sampler(lib, prefix, args, seed)
+    rows, window_ends = [], []
+    try:
+        so.set_trace(True); sp.set_trace(True)
+        for it in range(args.iter):
+            warm = it < args.warmup
+            if it == args.warmup:
+                so.disengage_adaptation(); sp.disengage_adaptation()
+            st = so.get_state()
+            if patch is not None:
+                sv = StateView(st)
+                if patch(it, sv):
+                    st = sv.bytes()
+                    so.set_state(st)
+            sp.set_state(st)
+            ro, rp = so.run(1, warm), sp.run(1, warm)
+            ctx = f"iteration {it}"
+            assert np.array_equal(so.get_trace(), sp.get_trace()), ctx + ": tree-move trace differs"
+            assert np.array_equal(ro["stan"][3:6], rp["stan"][3:6]), ctx + ": NUTS depth / n_leapfrog / divergent differ"
+            np.testing.assert_allclose(ro["stan"], rp["stan"], rtol=rtol, atol=atol, err_msg=ctx)
+            np.testing.assert_allclose(ro["bart"]["train"], rp["bart"]["train"], rtol=rtol, atol=atol, err_msg=ctx)
+            assert np.array_equal(ro["bart"]["varcount"], rp["bart"]["varcount"]), ctx
+            a, b = StateView(so.get_state()), StateView(sp.get_state())
+            if compare_states:
+                assert_state_parity(a, b, rtol=rtol, atol=atol)
+            if not np.array_equal(StateView(st).get("inv_metric"), a.get("inv_metric")):
+                window_ends.append(it)
+            rows.append(ro["stan"][:, 0].copy())
+    finally:
+        so.free(); sp.free()
+    return np.array(rows).T, window_ends
+
+
 def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True):
     """stan4bart_fit_worker (reference R/stan4bart_fit.R:33-60) with the diagnostics the parity tests compare."""
     import copy

@@ -167,6 +167,34 @@ class DevCpu {
       }
     }
   }
+  void assign_leaves_only() {
+    for (int t = 0; t < T_; ++t) {
+      TreeView tv = tree_view(a_, t);
+      for (size_t i = 0; i < n_; ++i) {
+        int nd = 0;
+        while (tv.var.get(nd) >= 0) nd = (xbin_[(size_t)tv.var.get(nd) * n_ + i] <= tv.cut.get(nd)) ? tv.left.get(nd) : tv.right.get(nd);
+        leaf_[(size_t)t * n_ + i] = (uint16_t)nd;
+      }
+    }
+  }
+  std::vector<double>& obs_array(int which) {
+    switch (which) {
+      case OBS_R: return R_;
+      case OBS_OFF: return off_;
+      case OBS_LAT: if (!binary_) throw std::invalid_argument("latents exist only for binary responses"); return lat_;
+      case OBS_Y: return y_;
+    }
+    throw std::invalid_argument("unknown observation array");
+  }
+  void download_obs(int which, double* out) { std::memcpy(out, obs_array(which).data(), n_ * 8); }
+  void upload_obs(int which, const double* in) {
+    if (which == OBS_Y) throw std::invalid_argument("the response is fixed at creation");
+    std::memcpy(obs_array(which).data(), in, n_ * 8);
+  }
+  void upload_counts(const int32_t* cnt) { std::memcpy(cnt_.data(), cnt, cnt_.size() * 4); }
+  void set_scale(double mn, double mx, double range, double sigmaData) {
+    scale_ = ScaleState{}; scale_.min = mn; scale_.max = mx; scale_.range = range; scale_.min0 = mn; scale_.range0 = range; scale_.sigmaData = sigmaData; scale_.sigma = sigmaData / range;
+  }
   void sweep(int thin) {
     for (int k = 0; k < thin; ++k) {
       propose_step(a_, 0); ++launches_;

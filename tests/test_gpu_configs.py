@@ -1,0 +1,100 @@
+"""BASELINE.json's configurations at their stated shape and size on the HIP path (VERDICT r01 `configs_untested`):
+  c3  Friedman n = 1e6, p = 50, ntree = 200, (1 + X4 | g.1) + (1 | g.2): oracle parity at full size, both gradient modes
+  c4  IHDP 747 x 25 mixed covariates, one 26-level group, probit: oracle parity, free-running and teacher-forced
+  c5  n = 1e7, P = 100, ntree = 400, 200 groups with random slopes: size-independent properties at full size,
+      oracle parity at n = 1e6 for the same shape
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_chain_parity, c5_case, friedman_case, ihdp_case, make_sampler, run_chain, teacher_forced
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_full_size_both_gradient_modes(oracle_lib, hip_lib):
+    """n = 1e6, p = 50, 200 trees, random slopes: 3 Gibbs iterations (600 tree updates, 3 NUTS transitions) against the oracle.
+    hmc_mode 0 evaluates the likelihood from s0 - 2 theta'c + theta'G theta, whose cancellation grows with N: compared here at
+    the full N against the oracle (which sums over the observations) and against hmc_mode 1 (per-leapfrog O(N) kernels)."""
+    args, _ = friedman_case(n=1_000_000, p=50, T=200, warmup=2, iter=3, slopes=True)
+    a = run_chain(oracle_lib, "orc_", args)
+    b0 = run_chain(hip_lib, "s4b_", args)
+    assert_chain_parity(a, b0)
+    args.hmc_mode = 1
+    b1 = run_chain(hip_lib, "s4b_", args)
+    assert_chain_parity(a, b1)
+    np.testing.assert_allclose(b0["sample"]["stan"], b1["sample"]["stan"], rtol=1e-6, atol=1e-9)
+    assert np.array_equal(b0["trace"], b1["trace"])
+
+
+def test_config4_ihdp_shape_probit(oracle_lib, hip_lib):
+    args = ihdp_case()
+    a = run_chain(oracle_lib, "orc_", args)
+    b = run_chain(hip_lib, "s4b_", args)
+    assert_chain_parity(a, b)
+    assert a["sample"]["bart"]["test"].shape == (747, 6) and "aux.1" not in b["names"]
+    assert sum(nm.startswith("b.") for nm in b["names"]) == 52          # 26 levels x (intercept, slope on z)
+    used = np.flatnonzero(a["sample"]["bart"]["varcount"].sum(axis=1))
+    assert (used >= 6).any()                                             # rules on binary covariates were accepted
+
+
+def test_config4_ihdp_teacher_forced(oracle_lib, hip_lib):
+    args = ihdp_case(warmup=40, iter=50, T=50)
+    args.adapt_init_buffer, args.adapt_term_buffer, args.adapt_window = 10, 10, 10
+    rows, ends = teacher_forced(oracle_lib, hip_lib, "s4b_", args)
+    assert ends == [19, 29], ends
+
+
+def test_config5_shape_at_1e6_matches_oracle(oracle_lib, hip_lib):
+    """P = 100, 400 trees, 200 groups with slopes (q = 400) at n = 1e6: 2 Gibbs iterations against the oracle."""
+    args, _ = c5_case(1_000_000, warmup=1, iter=2)
+    a = run_chain(oracle_lib, "orc_", args)
+    b = run_chain(hip_lib, "s4b_", args)
+    assert_chain_parity(a, b)
+    assert sum(nm.startswith("b.") for nm in b["names"]) == 400
+
+
+def test_config5_full_size_properties(hip_lib):
+    """n = 1e7, P = 100, 400 trees, q = 400 (BASELINE config 5 for one chain): properties that need no oracle — every tree's
+    leaf counts sum to n; test rows equal to training rows get identical fits; the fit returned by run() equals the fit
+    re-assembled from the flattened trees; a second chain from the same seed is bitwise identical."""
+    n, n_test, T = 10_000_000, 64, 400
+    args, xb = c5_case(n, warmup=2, iter=4, n_test=n_test, keep_fits=False)
+    xt = xb[:n_test].copy()
+    del xb
+    s = make_sampler(hip_lib, "s4b_", args)
+    s.run(2, True)
+    s.disengage_adaptation()
+    r = s.run(2, False)
+    tr, rng_state, rg = s.get_trees(), s.get_r_rng_state(), s.get_bart_data_range()
+    s.free()
+    roots = np.r_[True, tr["tree"][1:] != tr["tree"][:-1]]
+    assert roots.sum() == T and np.all(tr["n"][roots] == n)
+    leaf = tr["var"] < 0
+    assert np.array_equal(np.bincount(tr["tree"][leaf], weights=tr["n"][leaf], minlength=T), np.full(T, float(n)))
+    train = r["bart"]["train"][:, -1]
+    np.testing.assert_allclose(r["bart"]["test"][:, -1], train[:n_test], rtol=1e-9)
+    lo, hi = rg
+    fit = np.zeros(n_test)
+    starts = np.flatnonzero(roots)
+    for t in range(T):
+        var, val = tr["var"][starts[t]:], tr["value"][starts[t]:]
+        for i in range(n_test):
+            k = 0
+            while var[k] >= 0:
+                if xt[i, var[k]] <= val[k]:
+                    k += 1
+                else:
+                    depth, k = 1, k + 1
+                    while depth > 0:
+                        depth += 1 if var[k] >= 0 else -1
+                        k += 1
+            fit[i] += val[k]
+    np.testing.assert_allclose((fit + 0.5) * (hi - lo) + lo, train[:n_test], rtol=1e-8, atol=1e-8)
+    s2 = make_sampler(hip_lib, "s4b_", args)
+    s2.run(2, True)
+    s2.disengage_adaptation()
+    r2 = s2.run(2, False)
+    assert np.array_equal(rng_state, s2.get_r_rng_state())
+    s2.free()
+    assert np.array_equal(r2["bart"]["train"], r["bart"]["train"]) and np.array_equal(r2["stan"], r["stan"])

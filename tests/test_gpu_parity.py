@@ -142,14 +142,7 @@ def test_size_independent_invariants_at_scale(hip_lib):
     np.testing.assert_allclose((fit + 0.5) * (hi - lo) + lo, r["sample"]["bart"]["train"][:n_test, -1], rtol=1e-8, atol=1e-8)
 
 
-def _binary_case(n=200, T=11, warmup=7, iter=13, ranef=True, n_test=0):
-    from stan4bart_amd import GroupTerm, generate_friedman_data, make_sampler_args
-    d = generate_friedman_data(n, ranef=ranef, causal=True, binary=True)
-    x = d["x"]
-    xb = x[:, [0, 1, 2, 4, 5, 6, 7, 8, 9]]
-    groups = [GroupTerm(d["g1"], None), GroupTerm(d["g2"], None)] if ranef else []
-    return make_sampler_args(d["y"], xb, X=np.column_stack([x[:, 3], d["z"]]), groups=groups, family="binomial", iter=iter,
-                             warmup=warmup, x_test=xb[:n_test].copy() if n_test else None, bart_args={"n.trees": T})
+from conftest import binary_case as _binary_case  # noqa: E402
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(ranef=False), dict(n=747, T=50, n_test=25), dict(n=5001, T=20, warmup=3, iter=6)], ids=str)
