@@ -18,6 +18,9 @@ struct ScaleState {
 
 enum : int32_t { S4B_ERR_NODE_CAPACITY = 1, S4B_ERR_TRACE_OVERFLOW = 2, S4B_ERR_INTERNAL = 4 };
 
+// header of one scratch set: the pending proposal of the set's tree and (fused path) the scalars of the tree's snapshot
+struct StepHeader { Proposal pr; int32_t hwm, nl, ni, g, gn, valid; double logPi; };
+
 struct StepScratch {
   int16_t *pvar, *pleft, *pright, *pparent; uint16_t* pcut;
   int16_t *binA, *binB, *list; uint8_t* insub;
@@ -25,9 +28,14 @@ struct StepScratch {
   int16_t *pna, *pdep;                // node memo of the proposed tree (pointer path)
   double* work;                       // [7][2 nc] decide() work arrays (pointer path)
   int16_t* slab;                      // device: the nine int16 tables above are rows of one [SF_COUNT][nc] slab (one base address)
+  // fused path (one launch per tree update): the launch that proposes for tree t also snapshots tree t (rows SF_C* of the
+  // slab, leaf values, node sizes, header scalars); the next launch decides from the snapshot while its first workgroup
+  // writes the updated tree to the main arrays, so no workgroup ever reads what another one writes in the same launch
+  StepHeader* head; double* snapMu; int32_t* snapCnt;
 };
 // row order of the slabs (the individual pointers are views into them)
-enum { SF_VAR = 0, SF_CUT, SF_LEFT, SF_RIGHT, SF_PARENT, SF_NA, SF_DEP, SF_BINA, SF_BINB, SF_COUNT };
+enum { SF_VAR = 0, SF_CUT, SF_LEFT, SF_RIGHT, SF_PARENT, SF_NA, SF_DEP, SF_BINA, SF_BINB,
+       SF_CVAR, SF_CCUT, SF_CLEFT, SF_CRIGHT, SF_CPARENT, SF_CNA, SF_CDEP, SF_CLEAF, SF_CPRE, SF_CPOST, SF_COUNT };
 enum { TF_VAR = 0, TF_CUT, TF_LEFT, TF_RIGHT, TF_PARENT, TF_NA, TF_DEP, TF_LEAF, TF_PRE, TF_POST, TF_COUNT };
 enum { TI_HWM = 0, TI_NL, TI_NI, TI_G, TI_GN, TI_VALID, TI_COUNT };
 
@@ -64,6 +72,10 @@ struct BartArrays {
   double* binCnt; double* binSum;     // [binCap]
   const double* wts;                  // [n] observation weights or null (dbarts data@weights, Stan has_weights)
   double* partWt; double* binWt;      // weight totals per bin, only with weights
+  // fused path: partials double-buffered by step parity, [2][3 (sum, count, weight)][binCap][gridF]; generator slots
+  // rngF[2] (rng == &rngF[0] between sweeps); preDone[s] = the control step of the launch with parity s was already run
+  // by the tail of the previous launch (trees too large for the wave-register path); ticket counts finished workgroups
+  double* partF; int32_t gridF; MTState* rngF; int32_t* preDone; int32_t* ticket;
   MTState* rng; ScaleState* scale; const int32_t* numCuts;
   StepRecord* trace; int32_t* traceCount; int32_t* errFlag;
   ModelView model;             // numCuts inside points to device memory

@@ -800,6 +800,8 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
 #endif
 }
 
+#include "dev_step.inc"
+
 // ------------------------------------------------------------------------------------------------
 // k_apply: R_i += mu_old[leaf] - mu_new[leaf'], relabel observations under the accepted move's root
 __global__ __launch_bounds__(BLOCK) void k_apply(BartArrays a, int t) {
@@ -1419,7 +1421,8 @@ class DevHip {
       c.pvar = c.slab + SF_VAR * nc_; c.pcut = (uint16_t*)(c.slab + SF_CUT * nc_); c.pleft = c.slab + SF_LEFT * nc_; c.pright = c.slab + SF_RIGHT * nc_;
       c.pparent = c.slab + SF_PARENT * nc_; c.pna = c.slab + SF_NA * nc_; c.pdep = c.slab + SF_DEP * nc_; c.binA = c.slab + SF_BINA * nc_; c.binB = c.slab + SF_BINB * nc_;
       c.list = zalloc<int16_t>(nc_); c.insub = zalloc<uint8_t>(nc_);
-      c.muOld = zalloc<double>(nc_); c.prop = zalloc<Proposal>(1); c.accepted = zalloc<int32_t>(1);
+      c.muOld = zalloc<double>(nc_); c.head = zalloc<StepHeader>(1); c.prop = &c.head->pr; c.accepted = zalloc<int32_t>(1);
+      c.snapMu = zalloc<double>(nc_); c.snapCnt = zalloc<int32_t>(nc_);
       c.work = zalloc<double>((size_t)14 * nc_);
     }
     a.partCnt = zalloc<double>((size_t)a.binCap * a.grid); a.partSum = zalloc<double>((size_t)a.binCap * a.grid);
@@ -1428,7 +1431,19 @@ class DevHip {
       double* wt = alloc<double>((size_t)a.npad); HIP_OK(hipMemsetAsync(wt, 0, (size_t)a.npad * 8, stream_)); upload(wt, d.weights, (size_t)n_); a.wts = wt;
       a.partWt = zalloc<double>((size_t)a.binCap * a.grid); a.binWt = zalloc<double>((size_t)a.binCap);
     }
-    a.rng = zalloc<MTState>(1); a.scale = zalloc<ScaleState>(1);
+    a.rngF = zalloc<MTState>(2); a.rng = a.rngF; a.scale = zalloc<ScaleState>(1);
+    a.preDone = zalloc<int32_t>(2); a.ticket = zalloc<int32_t>(1);
+    {   // fused path (one launch per tree update, dev_step.inc): one 512-thread workgroup per CU at most
+      a.gridF = (int)std::min<int64_t>(256, std::max<int64_t>(1, (nQuads + F_PT - 1) / F_PT));
+      if (const char* g = getenv("S4B_GRIDF")) { int v = atoi(g); if (v >= 1 && v <= F_GRID_MAX) a.gridF = v; }
+      const int64_t perThread = (nQuads + (int64_t)a.gridF * F_PT - 1) / ((int64_t)a.gridF * F_PT);
+      ldsStep_ = step_lds_bytes(nc_, d.weights != nullptr);
+      // automatic choice: the fused launch wins while a tree update is latency-bound; at large n the two-kernel path keeps
+      // more waves streaming (4 per SIMD instead of 2)
+      useFused_ = perThread <= 8 && ldsStep_ + 24 * 1024 <= 160 * 1024;
+      if (const char* f = getenv("S4B_FUSED")) useFused_ = atoi(f) != 0 && perThread <= 255 && ldsStep_ + 24 * 1024 <= 160 * 1024;
+      a.partF = zalloc<double>((size_t)2 * 3 * a.binCap * a.gridF);
+    }
     int32_t* nc = alloc<int32_t>((size_t)P_); upload(nc, d.numCuts, (size_t)P_); a.numCuts = nc;
     a.trace = zalloc<StepRecord>((size_t)std::max(1, d.traceCap)); a.traceCount = zalloc<int32_t>(1); a.errFlag = zalloc<int32_t>(1);
     a.model = d.model; a.model.numCuts = nc; a.traceOn = 0; a.model.scratch = nullptr;
@@ -1462,6 +1477,9 @@ class DevHip {
     if (nTest_) testOut_ = zalloc<double>((size_t)nTest_);
     // ---- launch configuration
     gridN_ = a.grid;   // one launch geometry for every O(N) kernel: the partial buffers are sized by it
+#ifdef S4B_CONTROL_TIMING
+    { unsigned long long z[24] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_step), z, sizeof(z))); }
+#endif
     ldsApply_ = apply_lds_bytes(nc_); ldsTree_ = tree_lds_bytes(nc_); ldsControl_ = control_lds_bytes(P_, d.model.logIntLen);
     if (ldsTree_ > 64 * 1024) {
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
@@ -1470,6 +1488,10 @@ class DevHip {
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
     }
     if (ldsApply_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsApply_));
+    if (useFused_ && ldsStep_ > 32 * 1024) {
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsStep_));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsStep_));
+    }
     if (ldsTree_ > 160 * 1024) throw std::runtime_error("node_capacity too large for the 160 KiB LDS of a CU");
     // ---- initial scale from the raw response (offset 0), R = yRescaled
     if (binary_) { hipLaunchKernelGGL(k_init_binary, dim3(gridN_), dim3(BLOCK), 0, stream_, a_); ++launches_; }
@@ -1577,7 +1599,7 @@ class DevHip {
     if (useGraph_) {
       if (!graphExec_ || graphTrace_ != a_.traceOn) capture_sweep();
       for (int k = 0; k < thin; ++k) {
-        HIP_OK(hipGraphLaunch(graphExec_, stream_)); launches_ += 2 * T_ + 2;
+        HIP_OK(hipGraphLaunch(graphExec_, stream_)); launches_ += useFused_ ? T_ + 2 : 2 * T_ + 2;
         if (binary_) { hipLaunchKernelGGL(k_latents, dim3(1), dim3(BLOCK), 0, stream_, a_); ++launches_; }
       }
       return;
@@ -1604,7 +1626,26 @@ class DevHip {
       else hipLaunchKernelGGL((k_tree<true, false>), dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
     }
   }
+  void launch_step(int t) {
+    if (a_.wts) hipLaunchKernelGGL((k_step<true>), dim3(a_.gridF), dim3(FBLOCK), ldsStep_, stream_, a_, t);
+    else hipLaunchKernelGGL((k_step<false>), dim3(a_.gridF), dim3(FBLOCK), ldsStep_, stream_, a_, t);
+  }
+  // fused path: T + 1 launches per sweep (launch t: decide tree t-1, propose tree t, one O(N) pass), preceded by the
+  // one-workgroup launch that handles an oversized first tree
+  void sweep_fused_one() {
+    hipLaunchKernelGGL(k_step_pre, dim3(1), dim3(FBLOCK), 0, stream_, a_); ++launches_;
+    for (int t = 0; t <= T_; ++t) { launch_step(t); ++launches_; }
+    // the generator alternates between two slots by launch parity; between sweeps it lives in slot 0 (a_.rng)
+    if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_));
+  }
   void sweep_eager(int thin, bool withLatents) {
+    if (useFused_) {
+      for (int k = 0; k < thin; ++k) {
+        sweep_fused_one();
+        if (binary_ && withLatents) { hipLaunchKernelGGL(k_latents, dim3(1), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+      }
+      return;
+    }
     for (int k = 0; k < thin; ++k) {
       // per tree: one fused O(N) kernel (finish tree t-1, statistics of tree t) + one control kernel
       hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, -1, 0); ++launches_;
@@ -1618,7 +1659,48 @@ class DevHip {
     }
   }
   // per-launch HIP-event timing of extra sweeps on the sampler's stream (bench.py roofline leg)
+  void profile_sweep_fused(int nSweeps, int thin, double* out) {
+    std::vector<hipEvent_t> ev((size_t)2 * (T_ + 1));
+    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+    double sum = 0, cnt = 0, sumLast = 0, cntLast = 0;
+    for (int sIdx = 0; sIdx < nSweeps * thin; ++sIdx) {
+      hipLaunchKernelGGL(k_step_pre, dim3(1), dim3(FBLOCK), 0, stream_, a_); ++launches_;
+      for (int t = 0; t <= T_; ++t) {
+        HIP_OK(hipEventRecord(ev[(size_t)2 * t], stream_));
+        launch_step(t); ++launches_;
+        HIP_OK(hipEventRecord(ev[(size_t)2 * t + 1], stream_));
+      }
+      if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_));
+      if (binary_) { hipLaunchKernelGGL(k_latents, dim3(1), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+      sync();
+      for (int t = 0; t <= T_; ++t) {
+        float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[(size_t)2 * t], ev[(size_t)2 * t + 1]));
+        if (t >= 1 && t < T_) { sum += ms * 1000.0; cnt += 1; }            // launches with both halves
+        if (t == T_) { sumLast += ms * 1000.0; cntLast += 1; }
+      }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+#ifdef S4B_CONTROL_TIMING
+    { unsigned long long h[24]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_step), sizeof(h)));
+      const double k = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0;
+      fprintf(stderr, "DBG k_step us from the start of one workgroup (avg over %llu launches): reducers done %.2f | decider loads %.2f totals %.2f verdict posted %.2f decide %.2f stores %.2f | cand0: loads %.2f ready %.2f proposed %.2f verdict %.2f | arrival at the barrier: loaders %.2f cand0 %.2f cand1 %.2f | (iter %.0f) write-backs done %.2f | barrier %.2f pass done %.2f | pass (first bin pass): routing columns arrived +%.2f, prefetched quads done +%.2f (routing init +%.2f, deeper levels +%.2f [%.2f iterations], arithmetic +%.2f), block reduction + partials +%.2f\n",
+              h[0], h[1] * k, h[2] * k, h[3] * k, h[23] * k, h[4] * k, h[5] * k, h[19] * k, h[20] * k, h[21] * k, h[22] * k, h[16] * k, h[17] * k, h[18] * k, (double)h[6], h[7] * k, h[8] * k, h[9] * k, (double)(h[11] - h[10]) * k, (double)(h[12] - h[11]) * k, (double)(h[14] - h[11]) * k, (double)(h[15] - h[14]) * k, h[0] ? (double)h[6] / (double)h[0] : 0.0,
+              (double)(h[12] - h[15]) * k, (double)(h[13] - h[12]) * k);
+      unsigned long long z[24] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_step), z, sizeof(z))); }
+#endif
+    out[0] = cnt ? sum / cnt : 0.0; out[3] = cnt;        // the fused launch (statistics + control + apply)
+    out[1] = 0.0; out[4] = 0.0;                          // no separate control kernel
+    out[2] = cntLast ? sumLast / cntLast : 0.0; out[5] = cntLast;
+    HIP_OK(hipEventRecord(evStart_, stream_));
+    for (int sIdx = 0; sIdx < nSweeps; ++sIdx) sweep(thin);
+    HIP_OK(hipEventRecord(evStop_, stream_));
+    sync();
+    float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_));
+    out[6] = ms * 1000.0 / nSweeps;
+  }
+  bool fused() const { return useFused_; }
   void profile_sweep(int nSweeps, int thin, double* out) {
+    if (useFused_) { profile_sweep_fused(nSweeps, thin, out); return; }
     const int perSweep = 2 * T_ * thin + thin;
     std::vector<hipEvent_t> ev((size_t)perSweep * 2 + 4);
     for (auto& e : ev) HIP_OK(hipEventCreate(&e));
@@ -1798,7 +1880,7 @@ class DevHip {
 
   int device_ = 0; hipStream_t stream_ = nullptr; hipEvent_t evStart_ = nullptr, evStop_ = nullptr;
   int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1; bool binary_ = false;
-  size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0;
+  size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0; bool useFused_ = false;
   double dbgSweepMs_ = 0; int dbgSweeps_ = 0;
   hipGraph_t graph_ = nullptr; hipGraphExec_t graphExec_ = nullptr; int graphTrace_ = -1; bool useGraph_ = true;
   BartArrays a_; StanArrays s_;
