@@ -236,6 +236,11 @@ int S4B_FN(get_leaf_assignment)(s4b_sampler* s, int32_t tree, int32_t* out);
 /* counters: {log-density gradient evaluations, tree updates, device kernel launches} */
 int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
 
+/* NUTS totals over all transitions since creation: {transitions, sum of treedepth__, sum of n_leapfrog__, divergent transitions}
+ * (the per-draw values are columns 4-6 of the stan result; the totals let a caller that keeps no per-iteration output, keep_fits =
+ * FALSE, report mean tree depth and leapfrogs per iteration) */
+int S4B_FN(get_nuts_stats)(s4b_sampler* s, double out[4]);
+
 /* measurement hook (no reference counterpart): runs `n_sweeps` extra BART sweeps with HIP events recorded on the
  * sampler's own stream around every kernel launch and returns, per kernel class
  * {stats, control, apply}: out[0..2] = average launch duration in microseconds, out[3..5] = launches timed,

@@ -321,6 +321,10 @@ int orc_get_leaf_assignment(s4b_sampler* s, int32_t t, int32_t* out) {
 }
 int orc_get_counters(s4b_sampler* s, int64_t out[3]) { out[0] = s->model->gradEvals; out[1] = s->treeUpdates; out[2] = 0; return 0; }
 
+int orc_get_nuts_stats(s4b_sampler* s, double out[4]) {
+  out[0] = (double)s->nuts->tot_transitions; out[1] = (double)s->nuts->tot_depth; out[2] = (double)s->nuts->tot_leapfrog; out[3] = (double)s->nuts->tot_divergent;
+  return 0;
+}
 int orc_profile_sweep(s4b_sampler*, int32_t, double out[8]) { for (int i = 0; i < 8; ++i) out[i] = 0.0; return 0; }
 int orc_stream_probe(int32_t, int64_t, int32_t, double out[4]) { for (int i = 0; i < 4; ++i) out[i] = 0.0; return 0; }
 int orc_profile_leapfrog(s4b_sampler*, int32_t, double out[8]) { for (int i = 0; i < 8; ++i) out[i] = 0.0; return 0; }

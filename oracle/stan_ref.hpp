@@ -423,6 +423,7 @@ class NutsSampler {
   // current sample
   std::vector<double> cont_params; double lp_ = 0, accept_stat_ = 0;
   int num_skip;
+  long tot_transitions = 0, tot_depth = 0, tot_leapfrog = 0, tot_divergent = 0;
 
   NutsSampler(StanModel& m, const StanControl& c, unsigned chain, int num_warmup)
       : model(m), D(m.D), num_skip(c.skip) {
@@ -616,6 +617,7 @@ class NutsSampler {
       if (!persist) break;
     }
     n_leapfrog_ = n_leapfrog;
+    ++tot_transitions; tot_depth += depth_; tot_leapfrog += n_leapfrog; if (divergent_) ++tot_divergent;
     double accept_prob = sum_metro_prob / (double)n_leapfrog;
     z = z_sample;
     energy_ = H();

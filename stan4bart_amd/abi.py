@@ -271,7 +271,7 @@ class Sampler:
             "predict_bart_offset": [vp, dp, i64, dp, dp, C.POINTER(i64)],
             "get_state": [vp, vp, i64, C.POINTER(i64)], "set_state": [vp, vp, i64],
             "set_trace": [vp, i32], "get_trace": [vp, i64, ip, C.POINTER(i64)],
-            "get_leaf_assignment": [vp, i32, ip], "get_counters": [vp, C.POINTER(i64)],
+            "get_leaf_assignment": [vp, i32, ip], "get_counters": [vp, C.POINTER(i64)], "get_nuts_stats": [vp, dp],
             "profile_sweep": [vp, i32, dp], "profile_leapfrog": [vp, i32, dp],
             "set_progress": [vp, PROGRESS, vp],
         }
@@ -391,6 +391,12 @@ class Sampler:
         out = (C.c_int64 * 3)()
         self._check(self._f("get_counters")(self._h, out))
         return np.array(list(out), dtype=np.int64)
+
+    def get_nuts_stats(self) -> dict:
+        """Totals over all NUTS transitions since creation."""
+        out = (C.c_double * 4)()
+        self._check(self._f("get_nuts_stats")(self._h, out))
+        return dict(transitions=int(out[0]), sum_treedepth=int(out[1]), sum_n_leapfrog=int(out[2]), divergent=int(out[3]))
 
     def predict_bart(self, x_test: np.ndarray) -> np.ndarray:
         """``stan4bart_predictBART``: BART fit of every kept draw (keep_trees) at new rows, [n_test x samples]."""

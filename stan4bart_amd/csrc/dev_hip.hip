@@ -1247,6 +1247,105 @@ __global__ __launch_bounds__(BLOCK) void k_stan_finalize(BartArrays a, StanArray
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_stan_fused: every O(N) sum of one log-density / gradient evaluation in ONE pass and ONE launch
+// (reference: the likelihood part of continuous_model::log_prob, src/stan_files/continuous.hpp:2438-2470, evaluated once per
+// leapfrog through stan::math::gradient; SURVEY §8d B_lf = N (8K + 12z + 20) algorithmic bytes).
+//   DIRECT   (a leapfrog, hmc_mode 1):        e_i = e0_i - x_i'beta - z_i'b, nothing O(N) is written
+//   !DIRECT  (once per Gibbs iteration):      e_i = response_i - stanOffset_i from the BART state; e0 (and the fit) are written
+// and in both: ss = sum w e^2, X'(w e) (K columns, register accumulators), Z'(w e) (q columns).
+// Order-independent, hence deterministic, accumulation: every partial sum is split into two 64-bit fixed-point limbs
+// (2^-20 and 2^-56 units: together finer than the rounding of the double it came from) and added with INTEGER atomics — LDS
+// histogram for Z'e, per-XCD global accumulators for everything — so there are no per-workgroup partial arrays, no second
+// kernel and no finalize pass; the host adds the eight per-XCD copies (exact integer adds) after one small device-to-host copy.
+constexpr int SBLOCK = 256;
+constexpr int S_XCD = 8;
+constexpr int S_QMAX = 4096;          // Z'e histogram in LDS: 16 B per column (+ 8 B for b)
+struct FxLimbs { long long hi, lo; };
+__device__ __forceinline__ FxLimbs fx_split(double v) {
+  const double SH = 1048576.0, SL = 72057594037927936.0;   // 2^20, 2^56
+  const double h = rint(v * SH);
+  FxLimbs r; r.hi = (long long)h; r.lo = (long long)rint((v - h / SH) * SL);
+  return r;
+}
+struct StanFusedArgs {
+  unsigned long long* acc;    // [2][S_XCD][1 + K + q][2]: accumulators of this launch (parity) and of the next one (cleared here)
+  int32_t* bad;               // [2]: a partial sum left the fixed-point range (non-finite or > 2^42 in magnitude)
+  int32_t parity, mode, wantTrain;
+};
+template <int KMAX, bool DIRECT>
+__global__ __launch_bounds__(SBLOCK) void k_stan_fused(BartArrays a, StanArrays s, StanFusedArgs f) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* zh = (unsigned long long*)smem;                 // [q][2]
+  double* par = (double*)(smem + (size_t)s.q * 16);                   // [K + q] beta, b (DIRECT)
+  __shared__ double red[SBLOCK / 64][KMAX + 1];
+  const int K = s.K, q = s.q, M = 1 + K + q;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int j = threadIdx.x; j < 2 * q; j += SBLOCK) zh[j] = 0ull;
+  if (DIRECT) for (int j = threadIdx.x; j < K + q; j += SBLOCK) par[j] = s.params[j];
+  {   // clear the accumulators the NEXT evaluation uses (the host has consumed them: it synchronises on every evaluation)
+    unsigned long long* other = f.acc + (size_t)(1 - f.parity) * S_XCD * M * 2;
+    const size_t tot = (size_t)S_XCD * M * 2;
+    for (size_t j = (size_t)blockIdx.x * SBLOCK + threadIdx.x; j < tot; j += (size_t)gridDim.x * SBLOCK) other[j] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) f.bad[1 - f.parity] = 0;
+  }
+  __syncthreads();
+  const ScaleState sc = *a.scale;
+  double acc[KMAX + 1];
+#pragma unroll
+  for (int k = 0; k <= KMAX; ++k) acc[k] = 0.0;
+  int bad = 0;
+  const int64_t n = a.n;
+  for (int64_t i = (int64_t)blockIdx.x * SBLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SBLOCK) {
+    double xv[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) xv[k] = k < K ? s.X[(size_t)k * n + i] : 0.0;
+    const int e0i = q ? s.u[i] : 0, e1i = q ? s.u[i + 1] : 0;
+    double e;
+    if (DIRECT) {
+      double eta = 0.0;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) if (k < K) eta += xv[k] * par[k];
+      for (int z = e0i; z < e1i; ++z) eta += s.w[z] * par[K + s.v[z]];
+      e = s.e0[i] - eta;
+    } else {
+      double fit = 0.0, resp = a.y[i];
+      if (f.mode != 0 || f.wantTrain) {
+        if (a.binary) { const double zl = a.lat[i]; fit = zl - a.R[i]; if (f.mode != 0) resp = zl + a.off[i]; }
+        else { const double yr = (a.y[i] - a.off[i] - sc.min) / sc.range - 0.5; fit = ((yr - a.R[i]) + 0.5) * sc.range + sc.min; }
+      }
+      const double so = f.mode == 0 ? 0.0 : f.mode == 1 ? fit : f.mode == 2 ? a.userOffset[i] : fit + a.userOffset[i];
+      e = resp - so;
+      if (f.wantTrain) s.train[i] = fit;
+      s.e0[i] = e;
+    }
+    const double we = a.wts ? a.wts[i] * e : e;
+    acc[0] += we * e;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) if (k < K) acc[1 + k] += xv[k] * we;
+    for (int z = e0i; z < e1i; ++z) {
+      const double c = s.w[z] * we;
+      if (!(fabs(c) < 4398046511104.0)) { bad = 1; continue; }
+      const FxLimbs l = fx_split(c);
+      unsigned long long* dst = zh + 2 * (size_t)s.v[z];
+      atomicAdd(dst, (unsigned long long)l.hi); atomicAdd(dst + 1, (unsigned long long)l.lo);
+    }
+  }
+  // block reduction of ss and X'e in a fixed order, then the fixed-point hand-off
+#pragma unroll
+  for (int k = 0; k <= KMAX; ++k) { const double v = wave_sum(acc[k]); if (lane == 0) red[wv][k] = v; }
+  __syncthreads();
+  unsigned long long* mine = f.acc + ((size_t)f.parity * S_XCD + (blockIdx.x % S_XCD)) * M * 2;
+  if ((int)threadIdx.x <= K) {
+    const int k = threadIdx.x;
+    const double v = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    if (!(fabs(v) < 4398046511104.0)) bad = 1;
+    else { const FxLimbs l = fx_split(v); atomicAdd(mine + 2 * k, (unsigned long long)l.hi); atomicAdd(mine + 2 * k + 1, (unsigned long long)l.lo); }
+  }
+  for (int j = threadIdx.x; j < 2 * q; j += SBLOCK) { const unsigned long long v = zh[j]; if (v) atomicAdd(mine + 2 * (1 + K) + j, v); }
+  if (bad) atomicOr(f.bad + f.parity, 1);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_test_fits(BartArrays a, double* out) {
   const ScaleState sc = *a.scale;
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.nTest; i += (int64_t)gridDim.x * BLOCK) {
@@ -1338,6 +1437,7 @@ class DevHip {
     if (graph_) (void)hipGraphDestroy(graph_);
     for (void* p : allocs_) (void)hipFree(p);
     if (pinned_) (void)hipHostFree(pinned_);
+    if (pinnedAcc_) (void)hipHostFree(pinnedAcc_);
     if (stream_) (void)hipStreamDestroy(stream_);
     if (evStart_) { (void)hipEventDestroy(evStart_); (void)hipEventDestroy(evStop_); }
   }
@@ -1474,6 +1574,23 @@ class DevHip {
     s.out = zalloc<double>((size_t)(1 + K_ + q_));
     s.mmPart = zalloc<double>((size_t)2 * a.grid);
     HIP_OK(hipHostMalloc(&pinned_, sizeof(double) * (size_t)(2 * (1 + K_ + q_) + 64), hipHostMallocDefault));
+    {   // fused Stan sums: fixed-point accumulators (two parities, one copy per XCD), LDS histogram of Z'e
+      const size_t M = (size_t)(1 + K_ + q_);
+      fusedLds_ = (size_t)q_ * 16 + (size_t)(K_ + q_) * 8 + 16;
+      stanFused_ = K_ <= 16 && q_ <= S_QMAX;
+      if (const char* f = getenv("S4B_STAN_FUSED")) stanFused_ = stanFused_ && atoi(f) != 0;
+      if (stanFused_) {
+        fusedAcc_ = zalloc<unsigned long long>((size_t)2 * S_XCD * M * 2); fusedBad_ = zalloc<int32_t>(2);
+        HIP_OK(hipHostMalloc(&pinnedAcc_, sizeof(unsigned long long) * (S_XCD * M * 2 + 8), hipHostMallocDefault));
+        if (fusedLds_ > 48 * 1024) {
+          const void* fns[8] = {reinterpret_cast<const void*>(k_stan_fused<2, true>), reinterpret_cast<const void*>(k_stan_fused<2, false>),
+                                reinterpret_cast<const void*>(k_stan_fused<4, true>), reinterpret_cast<const void*>(k_stan_fused<4, false>),
+                                reinterpret_cast<const void*>(k_stan_fused<8, true>), reinterpret_cast<const void*>(k_stan_fused<8, false>),
+                                reinterpret_cast<const void*>(k_stan_fused<16, true>), reinterpret_cast<const void*>(k_stan_fused<16, false>)};
+          for (const void* fn : fns) HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fusedLds_));
+        }
+      }
+    }
     if (nTest_) testOut_ = zalloc<double>((size_t)nTest_);
     // ---- launch configuration
     gridN_ = a.grid;   // one launch geometry for every O(N) kernel: the partial buffers are sized by it
@@ -1774,15 +1891,48 @@ class DevHip {
 
   // ---- Stan inputs
   void stan_inputs(int mode, bool wantTrain, double* cX, double* cZ, double* s0, double* trainOut) {
-    reduce_pipeline(mode, wantTrain ? 1 : 0, 0);
-    fetch_out(cX, cZ, s0);
+    if (stanFused_) { launch_stan_fused(mode, wantTrain ? 1 : 0, false); fetch_fused(cX, cZ, s0); }
+    else { reduce_pipeline(mode, wantTrain ? 1 : 0, 0); fetch_out(cX, cZ, s0); }
     if (wantTrain && trainOut) { download(trainOut, s_.train, (size_t)n_); sync(); }
   }
   double leapfrog_sums(const double* beta, const double* b, double* gX, double* gZ) {
     push_params(beta, b);
-    reduce_pipeline(0, 0, 1);
-    double ss; fetch_out(gX, gZ, &ss);
+    double ss;
+    if (stanFused_) { launch_stan_fused(0, 0, true); fetch_fused(gX, gZ, &ss); }
+    else { reduce_pipeline(0, 0, 1); fetch_out(gX, gZ, &ss); }
     return ss;
+  }
+  // one launch per evaluation (k_stan_fused)
+  template <int KMAX> void launch_stan_fused_k(const StanFusedArgs& f, bool direct, size_t lds, int grid) {
+    if (direct) hipLaunchKernelGGL((k_stan_fused<KMAX, true>), dim3(grid), dim3(SBLOCK), lds, stream_, a_, s_, f);
+    else hipLaunchKernelGGL((k_stan_fused<KMAX, false>), dim3(grid), dim3(SBLOCK), lds, stream_, a_, s_, f);
+  }
+  void launch_stan_fused(int mode, int wantTrain, bool direct) {
+    StanFusedArgs f; f.acc = fusedAcc_; f.bad = fusedBad_; f.parity = fusedParity_; f.mode = mode; f.wantTrain = wantTrain;
+    const int grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n_ + SBLOCK - 1) / SBLOCK));
+    if (K_ <= 2) launch_stan_fused_k<2>(f, direct, fusedLds_, grid);
+    else if (K_ <= 4) launch_stan_fused_k<4>(f, direct, fusedLds_, grid);
+    else if (K_ <= 8) launch_stan_fused_k<8>(f, direct, fusedLds_, grid);
+    else launch_stan_fused_k<16>(f, direct, fusedLds_, grid);
+    ++launches_;
+  }
+  void fetch_fused(double* cX, double* cZ, double* s0) {
+    const size_t M = (size_t)(1 + K_ + q_);
+    HIP_OK(hipMemcpyAsync(pinnedAcc_, fusedAcc_ + (size_t)fusedParity_ * S_XCD * M * 2, S_XCD * M * 16, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipMemcpyAsync(pinnedAcc_ + S_XCD * M * 2, fusedBad_ + fusedParity_, 4, hipMemcpyDeviceToHost, stream_));
+    sync();
+    fusedParity_ ^= 1;
+    const bool bad = (*(const int32_t*)(pinnedAcc_ + S_XCD * M * 2)) != 0;
+    auto val = [&](size_t k) {
+      long long hi = 0, lo = 0;
+      for (int x = 0; x < S_XCD; ++x) { hi += (long long)pinnedAcc_[((size_t)x * M + k) * 2]; lo += (long long)pinnedAcc_[((size_t)x * M + k) * 2 + 1]; }
+      return (double)hi / 1048576.0 + (double)lo / 72057594037927936.0;
+    };
+    // a sum that left the fixed-point range (non-finite or astronomically large residuals: a trajectory far outside the typical set)
+    // is reported as a non-finite likelihood, which NUTS treats like the reference treats an exception: V = +inf (base_hamiltonian.hpp:61-70)
+    *s0 = bad ? std::numeric_limits<double>::infinity() : val(0);
+    for (int k = 0; k < K_; ++k) cX[k] = bad ? 0.0 : val((size_t)1 + k);
+    for (int j = 0; j < q_; ++j) cZ[j] = bad ? 0.0 : val((size_t)1 + K_ + j);
   }
 
   // HIP-event timing of the per-leapfrog O(N) sums (hmc_mode 1 path: e = e0 - X beta - Z b, |e|^2, X'e, Z'e) on the
@@ -1790,10 +1940,11 @@ class DevHip {
   // [2] kernel launches per evaluation
   void profile_leapfrog(int nEvals, const double* beta, const double* b, double* out) {
     push_params(beta, b);
-    reduce_pipeline(0, 0, 1); sync();                     // warm
+    if (stanFused_) { launch_stan_fused(0, 0, true); fusedParity_ ^= 1; } else reduce_pipeline(0, 0, 1);
+    sync();                                               // warm
     const int64_t l0 = launches_;
     HIP_OK(hipEventRecord(evStart_, stream_));
-    for (int i = 0; i < nEvals; ++i) reduce_pipeline(0, 0, 1);
+    for (int i = 0; i < nEvals; ++i) { if (stanFused_) { launch_stan_fused(0, 0, true); fusedParity_ ^= 1; } else reduce_pipeline(0, 0, 1); }
     HIP_OK(hipEventRecord(evStop_, stream_));
     sync();
     float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_));
@@ -1887,6 +2038,8 @@ class DevHip {
   std::vector<void*> allocs_;
   char* arena_ = nullptr; size_t arenaSize_ = 0, arenaUsed_ = 0;
   double* pinned_ = nullptr; double* testOut_ = nullptr;
+  unsigned long long* fusedAcc_ = nullptr; int32_t* fusedBad_ = nullptr; unsigned long long* pinnedAcc_ = nullptr;
+  size_t fusedLds_ = 0; int fusedParity_ = 0; bool stanFused_ = false;
   int64_t launches_ = 0;
 };
 

@@ -516,6 +516,7 @@ class SamplerCore {
     out[3] = (double)n_; out[4] = (double)n_ * (8.0 * K_ + 12.0 * z + 20.0);
     check_device();
   }
+  void nuts_stats(double out[4]) { live(); nuts_->totals(out); }
   void counters(int64_t out[3]) { live(); out[0] = model_->gradEvals; out[1] = treeUpdates_; out[2] = dev_.launches(); }
   Dev& dev() { return dev_; }
 

@@ -529,6 +529,8 @@ class Nuts {
     model_.write_array(cont_, row + 7);
   }
   void disengage() { adapting_ = false; nom_eps_ = std::exp(x_bar_); }
+  // running totals over all transitions since creation: {transitions, sum treedepth__, sum n_leapfrog__, divergent transitions}
+  void totals(double out[4]) const { out[0] = (double)nTrans_; out[1] = (double)sumDepth_; out[2] = (double)sumLeap_; out[3] = (double)nDiv_; }
 
   // Everything that carries over from one transition to the next (s4b_get_state / s4b_set_state: checkpoint / resume and
   // the teacher-forced parity tests).  Momentum, gradient and potential are recomputed at the start of a transition
@@ -578,6 +580,7 @@ class Nuts {
   double mu_ = 0.5, delta_ = 0.5, gamma_ = 0.05, kappa_ = 0.75, t0_ = 10, counter_ = 0, s_bar_ = 0, x_bar_ = 0;
   unsigned num_warmup_ = 0, init_buffer_ = 0, term_buffer_ = 0, base_window_ = 0, window_counter_ = 0, next_window_ = 0, window_size_ = 0;
   double wn_ = 0; V wm_, wm2_;
+  long nTrans_ = 0, sumDepth_ = 0, sumLeap_ = 0, nDiv_ = 0;
 
   double kinetic() const { double s = 0; for (int i = 0; i < D_; ++i) s += z_.p[(size_t)i] * (inv_metric_[(size_t)i] * z_.p[(size_t)i]); return 0.5 * s; }
   double hamiltonian() const { return kinetic() + z_.Vv; }
@@ -702,6 +705,7 @@ class Nuts {
       if (!ok) break;
     }
     n_leapfrog_ = acc.n_leapfrog;
+    ++nTrans_; sumDepth_ += depth_; sumLeap_ += acc.n_leapfrog; if (divergent_) ++nDiv_;
     accept_ = acc.sum_metro / (double)acc.n_leapfrog;
     z_ = sample;
     energy_ = hamiltonian();
