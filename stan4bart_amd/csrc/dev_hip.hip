@@ -1133,6 +1133,212 @@ __global__ __launch_bounds__(BLOCK) void k_latents(BartArrays a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_latents2 + k_latents_finish: the same probit latents, same stream positions, same generator state as k_latents, ~20x faster.
+// Which stream positions an observation consumes depends on where the previous observation stopped, but for a GIVEN start
+// everything about an observation is independent of the others.  So, per batch of 32 observations:
+//   build    (16 waves, lane-parallel): for observation i and every candidate start "slack" l = 0..63 (start position =
+//            batch base + 2 i + l: every observation consumes at least two positions, so only the surplus is uncertain) run
+//            the rejection logic on the position-indexed stream — table T[i][l] = slack the next observation starts with,
+//            X[i][l] = the accepted deviate;
+//   resolve  (one wave): the dependent chain collapses to o <- T[i][o]: one v_readlane per observation;
+//   finish   (separate, fully parallel kernel): latent = mean +- x, residual update.
+// The stream (tempered outputs U, and Z = the normal deviate a norm_rand() starting at each position returns) is produced
+// ahead, whole Mersenne-Twister blocks at a time, by all waves; a short history of blocks is kept so that the generator state
+// handed back is the one a sequential consumer would leave.
+constexpr int LB2 = 1024;
+constexpr int L_RING = 4096, L_CH = 2048, L_NB = 32, L_BLK = 8, L_EMAX = 20;
+struct Lat2Lds {
+  uint32_t (*mt)[626]; uint32_t* U; double* Z; double* E; uint8_t* EL; double* lower; double (*X)[64]; uint8_t (*T)[64];
+};
+static size_t lat2_lds_bytes() {
+  return (size_t)L_BLK * 626 * 4 + (size_t)L_RING * (4 + 8 + 8 + 1) + (size_t)L_CH * 8 + (size_t)L_NB * 64 * 8 + (size_t)L_NB * 64 + 64;
+}
+struct RingRng {   // position-indexed reader of the stream for the generic samplers (r_unif / r_exp)
+  const uint32_t* U; long long p;
+};
+__device__ __forceinline__ uint32_t mt_next(RingRng* r) {
+  const uint32_t y = r->U[r->p & (L_RING - 1)];
+  r->p += 1;
+  return y;
+}
+__global__ __launch_bounds__(LB2) void k_latents2(BartArrays a, double* xacc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Lat2Lds S;
+  {
+    unsigned char* b = smem;
+    S.Z = (double*)b; b += (size_t)L_RING * 8;
+    S.E = (double*)b; b += (size_t)L_RING * 8;
+    S.lower = (double*)b; b += (size_t)L_CH * 8;
+    S.X = (double (*)[64])b; b += (size_t)L_NB * 64 * 8;
+    S.mt = (uint32_t (*)[626])b; b += (size_t)L_BLK * 626 * 4;
+    S.U = (uint32_t*)b; b += (size_t)L_RING * 4;
+    S.EL = (uint8_t*)b; b += (size_t)L_RING;
+    S.T = (uint8_t (*)[64])b;
+  }
+  __shared__ long long shBase; __shared__ int shCnt, shStop;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // block 0 = the incoming state; absolute stream position g = 624 * block + index
+  for (int i = tid; i < 624; i += LB2) { const uint32_t v = a.rng->mt[i]; S.mt[0][i] = v; S.U[i] = mt_temper(v); }
+  long long base = a.rng->mti;          // position of the next draw
+  int nblk = 1;                         // blocks generated so far: positions [0, 624 nblk) exist
+  long long zHi = 0;                    // Z valid for positions < zHi, E / EL for positions < zHi - L_EMAX
+  long long eDone = 0;
+  __syncthreads();
+  const double BIG = 134217728.0;
+  // What depends on the stream position only, for every position, lane-parallel: Z[p] = the deviate a norm_rand() starting at p
+  // returns (2 positions), E[p] / EL[p] = the value an exp_rand() starting at p returns and the positions it consumes (<= 18)
+  auto refill = [&]() {   // uniform control flow: every thread executes the same sequence of barriers
+    bool any = false;
+    while ((long long)624 * nblk - base < 1536 && (long long)624 * (nblk + 1) - base <= L_RING) {
+      uint32_t* src = S.mt[(nblk - 1) % L_BLK]; uint32_t* dst = S.mt[nblk % L_BLK];
+      if (wv == 0) {
+        for (int i = lane; i < 624; i += 64) dst[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        mt_regenerate_wave((MTState*)dst);
+      }
+      __syncthreads();
+      for (int i = tid; i < 624; i += LB2) S.U[((long long)624 * nblk + i) & (L_RING - 1)] = mt_temper(dst[i]);
+      ++nblk; any = true;
+      __syncthreads();
+    }
+    if (!any && zHi != 0) return;
+    const long long genHi = (long long)624 * nblk;
+    const long long lo = zHi > base ? zHi : base;
+    for (long long p = lo + tid; p < genHi - 1; p += LB2) {
+      const double u1 = unif_fix(S.U[p & (L_RING - 1)]), u2 = unif_fix(S.U[(p + 1) & (L_RING - 1)]);
+      S.Z[p & (L_RING - 1)] = r_qnorm(((double)(int)(BIG * u1) + u2) / BIG);
+    }
+    const long long elo = eDone > base ? eDone : base;
+    for (long long p = elo + tid; p < genHi - L_EMAX; p += LB2) {
+      RingRng r; r.U = S.U; r.p = p;
+      S.E[p & (L_RING - 1)] = r_exp(&r);
+      S.EL[p & (L_RING - 1)] = (uint8_t)(r.p - p);
+    }
+    zHi = genHi - 1; eDone = genHi - L_EMAX;
+    __syncthreads();
+  };
+  for (int64_t c0 = 0; c0 < a.n; c0 += L_CH) {
+    const int chN = (int)((a.n - c0) < L_CH ? (a.n - c0) : L_CH);
+    __syncthreads();
+    for (int i = tid; i < chN; i += LB2) {   // truncation bound of every observation of the chunk
+      const int64_t g = c0 + i;
+      const double fOld = a.lat[g] - a.R[g], mean = fOld + a.off[g];
+      S.lower[i] = a.y[g] > 0.0 ? 0.0 - mean : mean - 0.0;
+    }
+    __syncthreads();
+    int done = 0;
+    while (done < chN) {
+#ifdef S4B_CONTROL_TIMING
+      const long long tl0 = wall_clock64();
+#endif
+      refill();
+#ifdef S4B_CONTROL_TIMING
+      const long long tl1 = wall_clock64();
+#endif
+      const int nbatch = (chN - done) < L_NB ? (chN - done) : L_NB;
+      // ---- build: one observation per wave at a time, lane = candidate slack
+      for (int i = wv; i < nbatch; i += LB2 / 64) {
+        const double lower = S.lower[done + i];
+        const long long p0 = base + 2 * i;
+        long long next; double x = 0.0; int bad = 0;
+        if (lower < 0.0) {
+          // norm_rand() until the deviate is >= lower: the first accepted position at or after the start with the start's parity.
+          // Acceptance of the 128 positions from p0 as two wave-wide bit masks; every lane then needs a shift and a count.
+          const long long pa = p0 + lane, pb = p0 + 64 + lane;
+          const double za = S.Z[pa & (L_RING - 1)], zb = S.Z[pb & (L_RING - 1)];
+          const unsigned long long ma = __ballot(pa < zHi && !(za < lower)), mb = __ballot(pb < zHi && !(zb < lower));
+          const unsigned long long win = lane == 0 ? ma : ((ma >> lane) | (mb << (64 - lane)));   // acceptance of positions pa, pa+1, ...
+          const unsigned long long cand = win & 0x5555555555555555ull;
+          if (cand != 0ull) {
+            const int k = __builtin_ctzll(cand);
+            x = S.Z[(pa + k) & (L_RING - 1)];
+            next = pa + k + 2;
+          } else {   // 32 rejections in a row (or the generated range ends): the plain loop
+            long long p = pa + 64;
+            for (;;) {
+              if (p >= zHi) { bad = 1; break; }
+              x = S.Z[p & (L_RING - 1)];
+              p += 2;
+              if (!(x < lower)) break;
+            }
+            next = p;
+            if (pa + 64 > zHi) bad = 1;
+          }
+        } else {
+          long long p = p0 + lane;
+          const double aa = 0.5 * (lower + sqrt(lower * lower + 4.0));
+          for (;;) {
+            if (p >= eDone) { bad = 1; break; }
+            const int len = S.EL[p & (L_RING - 1)];
+            x = S.E[p & (L_RING - 1)] / aa + lower;
+            const double u = unif_fix(S.U[(p + len) & (L_RING - 1)]);
+            p += len + 1;
+            const double d = x - aa;
+            if (!(u > exp(-0.5 * d * d))) break;
+          }
+          next = p;
+        }
+        const long long sl = next - (p0 + lane) + lane - 2;      // slack of the next observation
+        S.T[i][lane] = bad ? (uint8_t)255 : (uint8_t)(sl > 254 ? 254 : sl);
+        S.X[i][lane] = x;
+      }
+      __syncthreads();
+#ifdef S4B_CONTROL_TIMING
+      const long long tl2 = wall_clock64();
+#endif
+      // ---- resolve: o <- T[i][o]
+      if (wv == 0) {
+        int t[L_NB];
+#pragma unroll
+        for (int i = 0; i < L_NB; ++i) t[i] = i < nbatch ? (int)S.T[i][lane] : 255;
+        int o = 0, cnt = 0, alive = 1, mine = 0;
+#pragma unroll
+        for (int i = 0; i < L_NB; ++i) {
+          if (alive) {
+            const int nx = __builtin_amdgcn_readlane(t[i], o);
+            if (nx == 255) alive = 0;
+            else { mine = lane == i ? o : mine; ++cnt; o = nx; if (o >= 64) alive = 0; }
+          }
+        }
+        if (lane < cnt) xacc[c0 + done + lane] = S.X[lane][mine];
+        if (lane == 0) {
+          shBase = base + 2 * cnt + o; shCnt = cnt;
+          // no progress although the ring is as full as it can get: one observation would need thousands of positions
+          shStop = (cnt == 0 && (long long)624 * (nblk + 1) - base > L_RING && (long long)624 * nblk - base >= 1536) ? 1 : 0;
+        }
+      }
+      __syncthreads();
+      base = shBase; done += shCnt;
+      if (shStop) { if (tid == 0) *a.errFlag |= S4B_ERR_INTERNAL; done = chN; c0 = a.n; }
+#ifdef S4B_CONTROL_TIMING
+      if (tid == 0) { const long long tl3 = wall_clock64(); g_dbg[36] += tl1 - tl0; g_dbg[37] += tl2 - tl1; g_dbg[38] += tl3 - tl2; g_dbg[39] += 1; }
+#endif
+    }
+  }
+  __syncthreads();
+  // generator state after the last draw (lazy regeneration: a position on a block boundary stays in the old block, mti 624)
+  {
+    int b = (int)(base / 624), idx = (int)(base - (long long)b * 624);
+    if (idx == 0 && b > 0) { b -= 1; idx = 624; }
+    for (int k = tid; k < 624; k += LB2) a.rng->mt[k] = S.mt[b % L_BLK][k];
+    if (tid == 0) { a.rng->mti = idx; a.rng->pad = 0; }
+  }
+#ifdef S4B_CONTROL_TIMING
+  if (tid == 0) { printf("DBG k_latents2: %lld batches (%.1f obs each), per batch us: refill %.2f build %.2f resolve+sync %.2f\n", g_dbg[39], (double)a.n / (double)g_dbg[39],
+                         g_dbg[36] / 100.0 / g_dbg[39], g_dbg[37] / 100.0 / g_dbg[39], g_dbg[38] / 100.0 / g_dbg[39]); g_dbg[36] = g_dbg[37] = g_dbg[38] = g_dbg[39] = 0; }
+#endif
+}
+__global__ __launch_bounds__(BLOCK) void k_latents_finish(BartArrays a, const double* xacc) {
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK) {
+    const double fOld = a.lat[i] - a.R[i], offv = a.off[i], mean = fOld + offv, x = xacc[i];
+    const double z = a.y[i] > 0.0 ? mean + x : mean - x;
+    const double nl = z - offv;
+    a.lat[i] = nl; a.R[i] = nl - fOld;
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_init_binary(BartArrays a) {   // latents 2y - 1, no tree fits yet
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     ScaleState sc; sc.min = -0.5; sc.max = 0.5; sc.range = 1.0; sc.min0 = -0.5; sc.range0 = 1.0; sc.shiftPerTree = 0.0; sc.sigmaData = 1.0; sc.sigma = 1.0;
@@ -1496,7 +1702,14 @@ class DevHip {
     a.offNew = alloc<double>((size_t)a.npad); HIP_OK(hipMemsetAsync(a.offNew, 0, (size_t)a.npad * 8, stream_));
     if (d.userOffset) { double* uo = alloc<double>((size_t)a.npad); upload(uo, d.userOffset, (size_t)n_); a.userOffset = uo; }
     a.binary = d.binary; binary_ = d.binary != 0;
-    if (binary_) a.lat = zalloc<double>((size_t)a.npad);
+    if (binary_) {
+      a.lat = zalloc<double>((size_t)a.npad);
+      const char* lv = getenv("S4B_LATENTS");   // 1: the serial-bookkeeping kernel (k_latents), default: tables + readlane chain
+      if (!(lv && atoi(lv) == 1)) {
+        latX_ = zalloc<double>((size_t)a.npad);
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_latents2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lat2_lds_bytes()));
+      }
+    }
     a.leaf = alloc<uint16_t>((size_t)T_ * a.npad); HIP_OK(hipMemsetAsync(a.leaf, 0, (size_t)T_ * a.npad * 2, stream_));
     // ---- trees
     const size_t m = (size_t)T_ * nc_;
@@ -1717,7 +1930,7 @@ class DevHip {
       if (!graphExec_ || graphTrace_ != a_.traceOn) capture_sweep();
       for (int k = 0; k < thin; ++k) {
         HIP_OK(hipGraphLaunch(graphExec_, stream_)); launches_ += useFused_ ? T_ + 2 : 2 * T_ + 2;
-        if (binary_) { hipLaunchKernelGGL(k_latents, dim3(1), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+        if (binary_) launch_latents();
       }
       return;
     }
@@ -1743,6 +1956,13 @@ class DevHip {
       else hipLaunchKernelGGL((k_tree<true, false>), dim3(a_.grid), dim3(BLOCK), ldsTree_, stream_, a_, t);
     }
   }
+  void launch_latents() {
+    if (latX_) {
+      hipLaunchKernelGGL(k_latents2, dim3(1), dim3(LB2), lat2_lds_bytes(), stream_, a_, latX_);
+      hipLaunchKernelGGL(k_latents_finish, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, (const double*)latX_);
+      launches_ += 2;
+    } else { hipLaunchKernelGGL(k_latents, dim3(1), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+  }
   void launch_step(int t) {
     if (a_.wts) hipLaunchKernelGGL((k_step<true>), dim3(a_.gridF), dim3(FBLOCK), ldsStep_, stream_, a_, t);
     else hipLaunchKernelGGL((k_step<false>), dim3(a_.gridF), dim3(FBLOCK), ldsStep_, stream_, a_, t);
@@ -1759,7 +1979,7 @@ class DevHip {
     if (useFused_) {
       for (int k = 0; k < thin; ++k) {
         sweep_fused_one();
-        if (binary_ && withLatents) { hipLaunchKernelGGL(k_latents, dim3(1), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+        if (binary_ && withLatents) launch_latents();
       }
       return;
     }
@@ -1772,7 +1992,7 @@ class DevHip {
         launches_ += 2;
       }
       hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, T_ - 1); ++launches_;
-      if (binary_ && withLatents) { hipLaunchKernelGGL(k_latents, dim3(1), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+      if (binary_ && withLatents) launch_latents();
     }
   }
   // per-launch HIP-event timing of extra sweeps on the sampler's stream (bench.py roofline leg)
@@ -1788,7 +2008,7 @@ class DevHip {
         HIP_OK(hipEventRecord(ev[(size_t)2 * t + 1], stream_));
       }
       if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_));
-      if (binary_) { hipLaunchKernelGGL(k_latents, dim3(1), dim3(BLOCK), 0, stream_, a_); ++launches_; }
+      if (binary_) launch_latents();
       sync();
       for (int t = 0; t <= T_; ++t) {
         float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[(size_t)2 * t], ev[(size_t)2 * t + 1]));
@@ -2037,7 +2257,7 @@ class DevHip {
   BartArrays a_; StanArrays s_;
   std::vector<void*> allocs_;
   char* arena_ = nullptr; size_t arenaSize_ = 0, arenaUsed_ = 0;
-  double* pinned_ = nullptr; double* testOut_ = nullptr;
+  double* pinned_ = nullptr; double* testOut_ = nullptr; double* latX_ = nullptr;
   unsigned long long* fusedAcc_ = nullptr; int32_t* fusedBad_ = nullptr; unsigned long long* pinnedAcc_ = nullptr;
   size_t fusedLds_ = 0; int fusedParity_ = 0; bool stanFused_ = false;
   int64_t launches_ = 0;

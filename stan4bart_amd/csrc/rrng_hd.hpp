@@ -157,22 +157,30 @@ template <class RNG> S4B_HD inline double r_norm(RNG* s) {
   return r_qnorm(u / BIG);
 }
 
-// exp_rand() (Ahrens & Dieter 1972 as in R's sexp.c)
+// exp_rand() (Ahrens & Dieter 1972 as in R's sexp.c).  q[k] = sum_{i=1}^{k+1} log(2)^i / i!  — through a switch, not a local
+// array: a dynamically indexed local array lives in scratch (global) memory on the device, microseconds per access
+S4B_HD inline double r_exp_q(int i) {
+  switch (i) {
+    case 0: return 0.6931471805599453; case 1: return 0.9333736875190459; case 2: return 0.9888777961838675;
+    case 3: return 0.9984589039328340; case 4: return 0.9998292811061389; case 5: return 0.9999833164100727;
+    case 6: return 0.9999985691438767; case 7: return 0.9999998906925558; case 8: return 0.9999999924734159;
+    case 9: return 0.9999999995283275; case 10: return 0.9999999999728814; case 11: return 0.9999999999985598;
+    case 12: return 0.9999999999999289; case 13: return 0.9999999999999968; case 14: return 0.9999999999999999;
+    default: return 1.0000000000000000;
+  }
+}
 template <class RNG> S4B_HD inline double r_exp(RNG* s) {
-  const double q[16] = {0.6931471805599453, 0.9333736875190459, 0.9888777961838675, 0.9984589039328340,
-                        0.9998292811061389, 0.9999833164100727, 0.9999985691438767, 0.9999998906925558,
-                        0.9999999924734159, 0.9999999995283275, 0.9999999999728814, 0.9999999999985598,
-                        0.9999999999999289, 0.9999999999999968, 0.9999999999999999, 1.0000000000000000};
+  const double q0 = 0.6931471805599453;
   double a = 0.0;
   double u = r_unif(s);
   while (u <= 0.0 || u >= 1.0) u = r_unif(s);
-  for (;;) { u += u; if (u > 1.0) break; a += q[0]; }
+  for (;;) { u += u; if (u > 1.0) break; a += q0; }
   u -= 1.0;
-  if (u <= q[0]) return a + u;
+  if (u <= q0) return a + u;
   int i = 0;
   double ustar = r_unif(s), umin = ustar;
-  do { ustar = r_unif(s); if (umin > ustar) umin = ustar; ++i; } while (u > q[i]);
-  return a + umin * q[0];
+  do { ustar = r_unif(s); if (umin > ustar) umin = ustar; ++i; } while (u > r_exp_q(i));
+  return a + umin * q0;
 }
 
 // uniform integer in [lo, hi) the way dbarts' ext_rng does it: lo + (int64)(u * range)
