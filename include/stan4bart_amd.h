@@ -106,6 +106,10 @@ typedef struct {
 
 typedef int (*s4b_callback_fn)(void* user, const double* yhat_train, const double* yhat_test,
                                const double* stan_pars, int32_t num_pars);
+/* progress / cancellation hook of run(): called before iteration `iter` (1-based) of `num_iter` whenever iter is a multiple of
+ * common_control.refresh (every iteration when refresh <= 0); a non-zero return stops the run (status 1, "interrupted ...").
+ * Reference: "iter k / n" lines (src/init.cpp:752-754) and R_CheckUserInterrupt per transition (src/stan_sampler.hpp:44-48). */
+typedef int (*s4b_progress_fn)(void* user, int32_t iter, int32_t num_iter, int32_t is_warmup);
 
 /* the `commonControl` list (src/init.cpp:199-202, 1015-1051) */
 typedef struct {
@@ -180,6 +184,20 @@ int S4B_FN(get_trees)(s4b_sampler* s, int64_t cap, int32_t* tree, int32_t* n_obs
 int S4B_FN(get_kept_trees)(s4b_sampler* s, int64_t sample, int64_t cap, int32_t* sample_index, int32_t* tree, int32_t* n_obs,
                            int32_t* var, int32_t* split, double* value, int64_t* num_nodes);
 
+/* stan4bart_getTrees(chainIndices, sampleIndices, treeIndices, current = FALSE) — src/init.cpp:514-671 with its index vectors:
+ * 0-based draw / tree indices (NULL = all).  A sampler is one chain; the R shim loops over chainIndices. */
+int S4B_FN(get_kept_trees_indexed)(s4b_sampler* s, const int32_t* sample_idx, int64_t num_samples, const int32_t* tree_idx, int64_t num_trees,
+                                   int64_t cap, int32_t* sample_index, int32_t* tree, int32_t* n_obs, int32_t* var, int32_t* split, double* value,
+                                   int64_t* num_nodes);
+
+/* stan4bart_printTrees(chainIndices, sampleIndices, treeIndices) — src/init.cpp:448-512: prints the selected kept trees to stdout.
+ * The reference forwards to dbarts' printer, whose text format is not part of the reference tree: the layout here is this
+ * library's own (one node per line, indented by depth). */
+int S4B_FN(print_trees)(s4b_sampler* s, const int32_t* sample_idx, int64_t num_samples, const int32_t* tree_idx, int64_t num_trees);
+
+/* progress / cancellation hook (see s4b_progress_fn); fn = NULL removes it */
+int S4B_FN(set_progress)(s4b_sampler* s, s4b_progress_fn fn, void* user);
+
 /* stan4bart_exportBARTState — src/init.cpp:409-416 (+ R/stan4bart_fit.R:572-580): the trees kept while sampling (keep_trees),
  * the cut points and the response scales as one relocatable byte string, so that a chain fitted in another process can be
  * predicted from.  Call with buf = NULL (or cap too small) to learn the size. */
@@ -195,6 +213,8 @@ int S4B_FN(create_stored_bart_sampler)(const void* state, int64_t size, int32_t 
  * (reference: keepTrees is switched on only for the sampling phase, src/init.cpp:216-221,737-744).
  * out is n_test x num_samples (column-major); pass out = NULL to query num_samples. */
 int S4B_FN(predict_bart)(s4b_sampler* s, const double* x_test, int64_t n_test, double* out, int64_t* num_samples);
+/* the same with the reference's third argument: offset_test (n_test doubles, or NULL) is added to every draw's prediction */
+int S4B_FN(predict_bart_offset)(s4b_sampler* s, const double* x_test, int64_t n_test, const double* offset_test, double* out, int64_t* num_samples);
 
 /* Sampler state as one relocatable byte string: checkpoint / resume of a chain, and the hook of the teacher-forced parity
  * tests (state of one implementation injected into the other before every compared transition).  No reference routine

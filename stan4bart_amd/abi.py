@@ -268,7 +268,7 @@ class Sampler:
             "export_bart_state": [vp, vp, i64, C.POINTER(i64)],
             "create_stored_bart_sampler": [vp, i64, i32, C.POINTER(vp)],
             "predict_bart": [vp, dp, i64, dp, C.POINTER(i64)],
-            "predict_bart_offset": [vp, dp, i64, dp, dp, C.POINTER(i64)],
+            "predict_bart_offset": [vp, dp, i64, dp, dp, C.POINTER(i64)], "print_trees": [vp, ip, i64, ip, i64],
             "get_state": [vp, vp, i64, C.POINTER(i64)], "set_state": [vp, vp, i64],
             "set_trace": [vp, i32], "get_trace": [vp, i64, ip, C.POINTER(i64)],
             "get_leaf_assignment": [vp, i32, ip], "get_counters": [vp, C.POINTER(i64)], "get_nuts_stats": [vp, dp],
@@ -373,6 +373,37 @@ class Sampler:
                                               C.byref(nn)))
         return dict(sample=smp, tree=tree, n=nobs, var=var, split=split, value=value)
 
+    def get_kept_trees_indexed(self, sample_idx=None, tree_idx=None) -> dict:
+        """``stan4bart_getTrees(sampleIndices, treeIndices)``: 0-based index vectors (None = all, in order)."""
+        if not hasattr(self._lib, self._pfx + "get_kept_trees_indexed"):      # (the oracle exports the scalar form only)
+            parts = [self.get_kept_trees(-1)] if sample_idx is None else [self.get_kept_trees(int(k)) for k in sample_idx]
+            out = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+            if tree_idx is not None:
+                order = np.concatenate([np.flatnonzero((out["sample"] == sm) & (out["tree"] == t)) for sm in (np.unique(out["sample"]) if sample_idx is None else sample_idx) for t in tree_idx] or [np.zeros(0, dtype=np.int64)])
+                out = {k: v[order.astype(np.int64)] for k, v in out.items()}
+            return out
+        si = None if sample_idx is None else _i32(sample_idx)
+        ti = None if tree_idx is None else _i32(tree_idx)
+        args = (_ip(si), 0 if si is None else len(si), _ip(ti), 0 if ti is None else len(ti))
+        nn = C.c_int64()
+        self._check(self._f("get_kept_trees_indexed")(self._h, *args, 0, None, None, None, None, None, None, C.byref(nn)))
+        m = nn.value
+        smp, tree, nobs, var, split = (np.zeros(m, dtype=np.int32) for _ in range(5))
+        value = np.zeros(m)
+        self._check(self._f("get_kept_trees_indexed")(self._h, *args, m, _ip(smp), _ip(tree), _ip(nobs), _ip(var), _ip(split), _dp(value), C.byref(nn)))
+        return dict(sample=smp, tree=tree, n=nobs, var=var, split=split, value=value)
+
+    def print_trees(self, sample_idx=None, tree_idx=None):
+        si = None if sample_idx is None else _i32(sample_idx)
+        ti = None if tree_idx is None else _i32(tree_idx)
+        self._check(self._f("print_trees")(self._h, _ip(si), 0 if si is None else len(si), _ip(ti), 0 if ti is None else len(ti)))
+
+    def set_progress(self, fn):
+        """``fn(iter, num_iter, is_warmup) -> bool`` (True cancels the run), or None."""
+        self._progress_py = fn
+        self._progress_c = PROGRESS(lambda user, it, n, w: int(bool(fn(it, n, bool(w))))) if fn is not None else PROGRESS()
+        self._check(self._f("set_progress")(self._h, self._progress_c, None))
+
     def set_trace(self, enable: bool):
         self._check(self._f("set_trace")(self._h, int(enable)))
 
@@ -398,14 +429,20 @@ class Sampler:
         self._check(self._f("get_nuts_stats")(self._h, out))
         return dict(transitions=int(out[0]), sum_treedepth=int(out[1]), sum_n_leapfrog=int(out[2]), divergent=int(out[3]))
 
-    def predict_bart(self, x_test: np.ndarray) -> np.ndarray:
-        """``stan4bart_predictBART``: BART fit of every kept draw (keep_trees) at new rows, [n_test x samples]."""
+    def predict_bart(self, x_test: np.ndarray, offset_test: Optional[np.ndarray] = None) -> np.ndarray:
+        """``stan4bart_predictBART(x_test, offset_test)``: BART fit of every kept draw (keep_trees) at new rows, [n_test x samples]."""
         xt = _f64(x_test)
         ns = C.c_int64()
         self._check(self._f("predict_bart")(self._h, _dp(xt), xt.shape[0], None, C.byref(ns)))
         out = np.zeros((xt.shape[0], ns.value), order="F")
         if ns.value:
-            self._check(self._f("predict_bart")(self._h, _dp(xt), xt.shape[0], _dp(out), C.byref(ns)))
+            if offset_test is not None:
+                off = _f64(offset_test)
+                if off.shape != (xt.shape[0],):
+                    raise ValueError("length of offset_test must equal number of rows in x_test")
+                self._check(self._f("predict_bart_offset")(self._h, _dp(xt), xt.shape[0], _dp(off), _dp(out), C.byref(ns)))
+            else:
+                self._check(self._f("predict_bart")(self._h, _dp(xt), xt.shape[0], _dp(out), C.byref(ns)))
         return out
 
     def profile_leapfrog(self, n_evals: int = 10) -> dict:
@@ -470,6 +507,8 @@ class StoredSampler:
     predict_bart = Sampler.predict_bart
     export_bart_state = Sampler.export_bart_state
     get_kept_trees = Sampler.get_kept_trees
+    get_kept_trees_indexed = Sampler.get_kept_trees_indexed
+    print_trees = Sampler.print_trees
     free = Sampler.free
 
     def get_trees(self):

@@ -1581,7 +1581,8 @@ __global__ __launch_bounds__(BLOCK) void k_predict(const uint16_t* xb, int64_t n
       const PackedNode* base = nodes + treeStart[k * T + t];
       int nd = 0;
       PackedNode p = base[0];
-      while (p.var >= 0) { nd = (xb[(size_t)p.var * (size_t)nT + i] <= p.cut) ? p.left : p.right; p = base[nd]; }
+      // (states are validated when they are loaded; the step cap is a second guard against a walk that never ends)
+      for (int guard = 0; p.var >= 0 && guard < 32768; ++guard) { nd = (xb[(size_t)p.var * (size_t)nT + i] <= p.cut) ? p.left : p.right; p = base[nd]; }
       f += p.mu;
     }
     out[idx] = binary ? f : (f + 0.5) * scale[2 * k + 1] + scale[2 * k];

@@ -68,8 +68,35 @@ class SamplerCore {
     keptScale_.resize((size_t)S * 2); r.get(keptScale_.data(), keptScale_.size() * 8);
     keptTreeStart_.resize((size_t)S * (size_t)T_); r.get(keptTreeStart_.data(), keptTreeStart_.size() * 8);
     keptNodes_.resize((size_t)numNodes); r.get(keptNodes_.data(), keptNodes_.size() * sizeof(PackedNode));
-    for (int64_t st : keptTreeStart_) if (st < 0 || (uint64_t)st >= numNodes) throw std::invalid_argument("exported BART state: tree offset out of range");
-    for (const PackedNode& nd : keptNodes_) if (nd.var >= P_) throw std::invalid_argument("exported BART state: predictor index out of range");
+    // The byte string may come from another process (parallel.py gathers them across ranks) or from disk: nothing in it is
+    // trusted.  Every tree must be a contiguous node range whose links stay inside the range and form a tree (each node reached
+    // at most once from the root: no cycles, no shared children), with rules inside the cut tables — otherwise the prediction
+    // kernel would read out of bounds or never terminate.
+    {
+      const size_t numTreesAll = keptTreeStart_.size();
+      std::vector<uint8_t> seen; std::vector<int> stack;
+      for (size_t k = 0; k < numTreesAll; ++k) {
+        const int64_t st = keptTreeStart_[k];
+        const int64_t en = k + 1 < numTreesAll ? keptTreeStart_[k + 1] : (int64_t)numNodes;
+        if (st < 0 || en > (int64_t)numNodes || en <= st) throw std::invalid_argument("exported BART state: tree offset out of range");
+        const int64_t count = en - st;
+        if (count > 32767) throw std::invalid_argument("exported BART state: tree too large");
+        const PackedNode* base = keptNodes_.data() + st;
+        seen.assign((size_t)count, 0); stack.assign(1, 0);
+        while (!stack.empty()) {
+          const int nd = stack.back(); stack.pop_back();
+          if (seen[(size_t)nd]) throw std::invalid_argument("exported BART state: node reached twice (cycle or shared child)");
+          seen[(size_t)nd] = 1;
+          const PackedNode& p = base[nd];
+          if (p.var >= 0) {
+            if (p.var >= P_) throw std::invalid_argument("exported BART state: predictor index out of range");
+            if ((int)p.cut >= numCuts_[(size_t)p.var]) throw std::invalid_argument("exported BART state: cut index out of range");
+            if (p.left < 0 || p.left >= count || p.right < 0 || p.right >= count) throw std::invalid_argument("exported BART state: child link out of range");
+            stack.push_back(p.right); stack.push_back(p.left);
+          } else if (p.var != NODE_LEAF) throw std::invalid_argument("exported BART state: unused slot linked into a tree");
+        }
+      }
+    }
     dev_.init_stored(device, P_);
   }
   // stan4bart_exportBARTState (reference src/init.cpp:409-416): needed size; written when the buffer is large enough
@@ -109,7 +136,7 @@ class SamplerCore {
     if ((sd->prior_dist == 3 || sd->prior_dist == 4) && cc->is_binary) throw std::invalid_argument("hs priors scale with the residual sd: not available for binary responses");
     if (sd->prior_dist == 7 && !sd->num_normals) throw std::invalid_argument("product_normal needs num_normals");
     n_ = (size_t)bd->n; P_ = bd->p; T_ = bc->n_trees; nTest_ = (size_t)bd->n_test;
-    warmup_ = cc->warmup; verbose_ = cc->verbose; keepFits_ = cc->keep_fits != 0; offsetType_ = cc->offset_type;
+    warmup_ = cc->warmup; verbose_ = cc->verbose; refresh_ = cc->refresh; keepFits_ = cc->keep_fits != 0; offsetType_ = cc->offset_type;
     callback_ = cc->callback; callbackUser_ = cc->callback_user;
     thin_ = bc->n_thin > 0 ? bc->n_thin : 1;
     keepTrees_ = bc->keep_trees != 0;
@@ -224,10 +251,22 @@ class SamplerCore {
     const bool lastOnly = !keepFits_ && !callback_;
     if (wantTrain) train.resize(n_);
     if (nTest_) test.resize(nTest_);
+    // reference src/init.cpp:745-747, 752-754: start line at verbose > 0, "iter k / n" every `refresh` iterations at verbose > 1.
+    // With a progress hook (s4b_set_progress) the hook is called instead of printing, every `refresh` iterations (every
+    // iteration when refresh <= 0), and may cancel the run by returning non-zero (the R shim polls R_CheckUserInterrupt there,
+    // as the reference does per transition: src/stan_sampler.hpp:44-48)
+    if (verbose_ > 0 && !progress_)
+      std::printf("starting %s, %d draws, %s\n", isWarmup ? "warmup" : "sampling", numIter,
+                  resultsType == 0 ? "both BART and Stan" : (resultsType == 1 ? "BART only" : "Stan only"));
+    std::fflush(stdout);
     const bool timing = std::getenv("S4B_HOST_TIMING") != nullptr;
     double tph[4] = {0, 0, 0, 0};
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int iter = 0; iter < numIter; ++iter) {
+      if (progress_) {
+        if (refresh_ <= 0 || (iter + 1) % refresh_ == 0 || iter == 0)
+          if (progress_(progressUser_, iter + 1, numIter, isWarmup ? 1 : 0) != 0) throw std::runtime_error("interrupted by the progress callback");
+      } else if (refresh_ > 0 && verbose_ > 1 && (iter + 1) % refresh_ == 0) { std::printf("  iter %.3d / %.3d\n", iter + 1, numIter); std::fflush(stdout); }
       double t0 = timing ? now() : 0;
       if (doStan) {
         nuts_->run(row_.data());
@@ -274,6 +313,7 @@ class SamplerCore {
   }
 
   void disengage_adaptation() { live(); nuts_->disengage(); }
+  void set_progress(s4b_progress_fn fn, void* user) { progress_ = fn; progressUser_ = user; }
 
   void parametric_mean(double* out) {
     live();
@@ -328,32 +368,76 @@ class SamplerCore {
     }
     return cnt;
   }
-  // stan4bart_getTrees(current = FALSE) over the kept draws (reference src/init.cpp:514-671; extract(fit, "trees", sampleNums = )):
-  // sample < 0: every kept draw, else that one (0-based); same flattened layout as get_trees plus the draw index
-  int64_t get_kept_trees(int64_t sample, int64_t cap, int32_t* smp, int32_t* tree, int32_t* n_obs, int32_t* var, int32_t* split, double* value) const {
+  // stan4bart_getTrees(current = FALSE) over the kept draws (reference src/init.cpp:514-671; extract(fit, "trees", sampleNums = , treeNums = )):
+  // 0-based index vectors select draws / trees (NULL = all, in order); same flattened layout as get_trees plus the draw index
+  int64_t get_kept_trees_indexed(const int32_t* sampleIdx, int64_t numSamples, const int32_t* treeIdx, int64_t numTrees, int64_t cap, int32_t* smp,
+                                 int32_t* tree, int32_t* n_obs, int32_t* var, int32_t* split, double* value) const {
     const int64_t S = (int64_t)keptScale_.size() / 2;
-    if (sample >= S) throw std::invalid_argument("sample index out of range");
+    if (sampleIdx && numSamples > S) throw std::invalid_argument(std::to_string(numSamples) + " samples specified but only " + std::to_string(S) + " in sampler");
+    if (treeIdx && numTrees > T_) throw std::invalid_argument(std::to_string(numTrees) + " trees specified but only " + std::to_string(T_) + " in sampler");
+    const int64_t nS = sampleIdx ? numSamples : S, nT = treeIdx ? numTrees : (int64_t)T_;
     int64_t cnt = 0;
     std::vector<int> stack;
-    for (int64_t k = sample < 0 ? 0 : sample; k < (sample < 0 ? S : sample + 1); ++k) for (int t = 0; t < T_; ++t) {
-      const PackedNode* base = keptNodes_.data() + keptTreeStart_[(size_t)(k * T_ + t)];
-      stack.assign(1, 0);
-      while (!stack.empty()) {   // preorder
-        const int nd = stack.back(); stack.pop_back();
-        const PackedNode& p = base[nd];
-        if (cnt < cap && tree) {
-          smp[cnt] = (int32_t)k; tree[cnt] = t; n_obs[cnt] = p.n;
-          if (p.var >= 0) { var[cnt] = p.var; split[cnt] = p.cut; value[cnt] = cuts_[(size_t)p.var][(size_t)p.cut]; }
-          else { var[cnt] = -1; split[cnt] = -1; value[cnt] = p.mu; }
+    for (int64_t a = 0; a < nS; ++a) {
+      const int64_t k = sampleIdx ? (int64_t)sampleIdx[a] : a;
+      if (k < 0 || k >= S) throw std::invalid_argument("sample index out of range");
+      for (int64_t b = 0; b < nT; ++b) {
+        const int t = treeIdx ? (int)treeIdx[b] : (int)b;
+        if (t < 0 || t >= T_) throw std::invalid_argument("tree index out of range");
+        const PackedNode* base = keptNodes_.data() + keptTreeStart_[(size_t)(k * T_ + t)];
+        stack.assign(1, 0);
+        while (!stack.empty()) {   // preorder
+          const int nd = stack.back(); stack.pop_back();
+          const PackedNode& p = base[nd];
+          if (cnt < cap && tree) {
+            smp[cnt] = (int32_t)k; tree[cnt] = t; n_obs[cnt] = p.n;
+            if (p.var >= 0) { var[cnt] = p.var; split[cnt] = p.cut; value[cnt] = cuts_[(size_t)p.var][(size_t)p.cut]; }
+            else { var[cnt] = -1; split[cnt] = -1; value[cnt] = p.mu; }
+          }
+          ++cnt;
+          if (p.var >= 0) { stack.push_back(p.right); stack.push_back(p.left); }
         }
-        ++cnt;
-        if (p.var >= 0) { stack.push_back(p.right); stack.push_back(p.left); }
       }
     }
     return cnt;
   }
+  int64_t get_kept_trees(int64_t sample, int64_t cap, int32_t* smp, int32_t* tree, int32_t* n_obs, int32_t* var, int32_t* split, double* value) const {
+    const int64_t S = (int64_t)keptScale_.size() / 2;
+    if (sample >= S) throw std::invalid_argument("sample index out of range");
+    if (sample < 0) return get_kept_trees_indexed(nullptr, 0, nullptr, 0, cap, smp, tree, n_obs, var, split, value);
+    const int32_t one = (int32_t)sample;
+    return get_kept_trees_indexed(&one, 1, nullptr, 0, cap, smp, tree, n_obs, var, split, value);
+  }
+  // stan4bart_printTrees (reference src/init.cpp:448-512 hands the indices to dbarts' printer, whose text format is not part of
+  // the reference tree): one line per node, indented by depth — "var <= cut value [n]" for rules, "mu [n]" for leaves
+  void print_trees(const int32_t* sampleIdx, int64_t numSamples, const int32_t* treeIdx, int64_t numTrees) const {
+    const int64_t S = (int64_t)keptScale_.size() / 2;
+    const int64_t nS = sampleIdx ? numSamples : S, nT = treeIdx ? numTrees : (int64_t)T_;
+    if (sampleIdx && numSamples > S) throw std::invalid_argument(std::to_string(numSamples) + " samples specified but only " + std::to_string(S) + " in sampler");
+    if (treeIdx && numTrees > T_) throw std::invalid_argument(std::to_string(numTrees) + " trees specified but only " + std::to_string(T_) + " in sampler");
+    std::vector<std::pair<int, int>> stack;
+    for (int64_t a = 0; a < nS; ++a) {
+      const int64_t k = sampleIdx ? (int64_t)sampleIdx[a] : a;
+      if (k < 0 || k >= S) throw std::invalid_argument("sample index out of range");
+      for (int64_t b = 0; b < nT; ++b) {
+        const int t = treeIdx ? (int)treeIdx[b] : (int)b;
+        if (t < 0 || t >= T_) throw std::invalid_argument("tree index out of range");
+        std::printf("sample %lld tree %d:\n", (long long)k + 1, t + 1);
+        const PackedNode* base = keptNodes_.data() + keptTreeStart_[(size_t)(k * T_ + t)];
+        stack.assign(1, std::make_pair(0, 0));
+        while (!stack.empty()) {
+          const int nd = stack.back().first, depth = stack.back().second; stack.pop_back();
+          const PackedNode& p = base[nd];
+          for (int d = 0; d < depth; ++d) std::printf("  ");
+          if (p.var >= 0) { std::printf("x%d <= %g [n = %d]\n", p.var + 1, cuts_[(size_t)p.var][(size_t)p.cut], p.n); stack.push_back(std::make_pair((int)p.right, depth + 1)); stack.push_back(std::make_pair((int)p.left, depth + 1)); }
+          else std::printf("mu = %g [n = %d]\n", p.mu, p.n);
+        }
+      }
+    }
+    std::fflush(stdout);
+  }
   // stan4bart_predictBART over the trees kept while sampling (reference src/init.cpp:354-403)
-  int64_t predict(const double* xTest, int64_t nT, double* out) {
+  int64_t predict(const double* xTest, int64_t nT, double* out, const double* offsetTest = nullptr) {
     const int64_t S = (int64_t)keptScale_.size() / 2;
     if (!out) return S;
     if (nT < 1 || !xTest) throw std::invalid_argument("predict: x_test must have at least one row");
@@ -361,6 +445,8 @@ class SamplerCore {
     std::vector<uint16_t> xb((size_t)P_ * (size_t)nT);
     bin_matrix(xTest, (size_t)nT, xb);
     dev_.predict_stored(xb.data(), nT, keptNodes_.data(), keptNodes_.size(), keptTreeStart_.data(), S, T_, keptScale_.data(), binary_ ? 1 : 0, out);
+    // offset_test of stan4bart_predictBART (reference src/init.cpp:377-384): added to every draw's prediction
+    if (offsetTest) for (int64_t k = 0; k < S; ++k) for (int64_t i = 0; i < nT; ++i) out[(size_t)k * (size_t)nT + (size_t)i] += offsetTest[i];
     return S;
   }
   // ---- sampler state as a byte string (layout: include/stan4bart_amd.h, s4b_get_state)
@@ -676,7 +762,7 @@ class SamplerCore {
 
   Dev dev_;
   size_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 256, thin_ = 1, K_ = 0, q_ = 0, hmcMode_ = 0;
-  int warmup_ = 0, verbose_ = 0, offsetType_ = 0; bool keepFits_ = true, hasUserOffset_ = false, binary_ = false;
+  int warmup_ = 0, verbose_ = 0, refresh_ = 0, offsetType_ = 0; s4b_progress_fn progress_ = nullptr; void* progressUser_ = nullptr; bool keepFits_ = true, hasUserOffset_ = false, binary_ = false;
   std::vector<double> userOffset_;
   s4b_callback_fn callback_ = nullptr; void* callbackUser_ = nullptr;
   MTState rng_;

@@ -171,12 +171,12 @@ class Stan4bartFit:
             for c, smp in enumerate(self.samplers):
                 if chain_nums is not None and c not in np.atleast_1d(chain_nums):
                     continue
-                parts = ([smp.get_kept_trees(-1)] if sample_nums is None else [smp.get_kept_trees(int(k)) for k in np.atleast_1d(sample_nums)])
-                for tr in parts:
-                    keep = np.ones(len(tr["tree"]), dtype=bool) if tree_nums is None else np.isin(tr["tree"], np.atleast_1d(tree_nums))
-                    cols["chain"].append(np.full(int(keep.sum()), c, dtype=np.int32))
-                    for k in ("sample", "tree", "n", "var", "split", "value"):
-                        cols[k].append(tr[k][keep])
+                # the index vectors go to the C boundary as they are (stan4bart_getTrees takes them: reference src/init.cpp:514-671)
+                tr = smp.get_kept_trees_indexed(None if sample_nums is None else np.atleast_1d(sample_nums),
+                                                None if tree_nums is None else np.atleast_1d(tree_nums))
+                cols["chain"].append(np.full(len(tr["tree"]), c, dtype=np.int32))
+                for k in ("sample", "tree", "n", "var", "split", "value"):
+                    cols[k].append(tr[k])
             return {k: np.concatenate(v) if v else np.zeros(0) for k, v in cols.items()}
         if sample not in ("train", "test"):
             raise ValueError("'sample' must be 'train' or 'test'")

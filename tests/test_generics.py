@@ -161,6 +161,22 @@ def _check_stored(fit, data, lib, prefix):
         StoredSampler(lib, prefix, states[0][: len(states[0]) // 2])
     with pytest.raises(RuntimeError, match="exported"):
         StoredSampler(lib, prefix, b"\x00" * 64)
+    # crafted / corrupted states must be rejected at load time (they would make the prediction kernel read out of bounds or loop):
+    # the node records are the tail of the product's byte string, 24 bytes each: {int16 var, uint16 cut, int16 left, int16 right,
+    # double mu, int32 n, pad} (the oracle has its own layout)
+    if prefix != "orc_":
+        import struct
+        raw = bytearray(states[0])
+        P, T = struct.unpack_from("<II", raw, 8)
+        S, num_nodes = struct.unpack_from("<QQ", raw, 20)
+        node0 = len(raw) - 24 * num_nodes
+        k = next(j for j in range(num_nodes) if struct.unpack_from("<h", raw, node0 + 24 * j)[0] >= 0)    # an internal node
+        left = struct.unpack_from("<h", raw, node0 + 24 * k + 4)[0]
+        for offset, fmt, value in ((4, "<h", 30000), (6, "<h", left), (0, "<h", P + 3), (2, "<H", 65000)):
+            bad = bytearray(raw)                # child link out of range / both links to one child / predictor / cut out of range
+            struct.pack_into(fmt, bad, node0 + 24 * k + offset, value)
+            with pytest.raises(RuntimeError, match="exported BART state"):
+                StoredSampler(lib, prefix, bytes(bad))
     fit.close()
 
 

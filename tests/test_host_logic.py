@@ -252,3 +252,47 @@ def test_config5_shape_many_predictors_and_groups(oracle_lib, emul_lib, P):
 def test_one_and_two_trees(oracle_lib, emul_lib, T):
     args, _ = friedman_case(T=T, warmup=10, iter=30, ranef=False)
     assert_chain_parity(run_chain(oracle_lib, "orc_", args), run_chain(emul_lib, "emu_", args))
+
+
+def test_interface_details_of_the_call_layer(emul_lib, capfd):
+    """getTrees with index vectors, predictBART(offset_test), printTrees, progress / cancellation hook, verbose output
+    (reference src/init.cpp:354-403, 448-671, 745-754; src/stan_sampler.hpp:44-48)."""
+    from conftest import make_sampler
+    args, d = friedman_case(n=150, T=6, warmup=4, iter=10, bart_args={"keepTrees": True})
+    s = make_sampler(emul_lib, "emu_", args)
+    s.run(4, True)
+    s.disengage_adaptation()
+    s.run(6, False)
+    allt = s.get_kept_trees(-1)
+    sel = s.get_kept_trees_indexed([4, 1], [5, 0, 2])
+    want = np.concatenate([np.flatnonzero((allt["sample"] == k) & (allt["tree"] == t)) for k in (4, 1) for t in (5, 0, 2)])
+    for k in allt:
+        assert np.array_equal(sel[k], allt[k][want]), k
+    assert np.array_equal(s.get_kept_trees_indexed(None, None)["value"], allt["value"])
+    with pytest.raises(RuntimeError, match="samples specified but only 6"):
+        s.get_kept_trees_indexed(list(range(7)), None)
+    with pytest.raises(RuntimeError, match="tree index out of range"):
+        s.get_kept_trees_indexed(None, [6])
+    xt = np.asfortranarray(args.x_bart[:9])
+    off = np.linspace(-1, 1, 9)
+    np.testing.assert_allclose(s.predict_bart(xt, off), s.predict_bart(xt) + off[:, None], rtol=0, atol=1e-12)
+    capfd.readouterr()
+    s.print_trees([0], [1])
+    out = capfd.readouterr().out
+    assert out.startswith("sample 1 tree 2:") and ("mu = " in out)
+    # progress hook: called at refresh multiples, a True return cancels the run
+    seen = []
+    s.set_progress(lambda it, n, w: (seen.append((it, n, w)), it >= 3)[1])
+    with pytest.raises(RuntimeError, match="interrupted"):
+        s.run(5, False)
+    assert seen[-1] == (3, 5, False)
+    s.set_progress(None)
+    s.free()
+    # verbose / refresh without a hook: the reference's lines
+    args.verbose, args.refresh = 2, 2
+    s = make_sampler(emul_lib, "emu_", args)
+    capfd.readouterr()
+    s.run(4, True)
+    out = capfd.readouterr().out
+    assert "starting warmup, 4 draws, both BART and Stan" in out and "iter 002 / 004" in out and "iter 004 / 004" in out
+    s.free()
