@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/stan4bart_amd.h"
@@ -723,20 +724,43 @@ class SamplerCore {
   // factor never co-occur), so G is kept in CSR form: a leapfrog costs O(nnz(G)), not O((K+q)^2).
   void build_gram(const s4b_stan_data* sd) {
     const int M = K_ + q_;
-    std::vector<double> dense((size_t)M * M, 0.0);
     std::vector<int> idx; std::vector<double> val;
-    for (int64_t i = 0; i < sd->N; ++i) {
+    auto row_of = [&](int64_t i) {
       idx.clear(); val.clear();
       for (int k = 0; k < K_; ++k) { idx.push_back(k); val.push_back(sd->X[(size_t)k * sd->N + i]); }
       if (q_) for (int e = sd->u[i]; e < sd->u[i + 1]; ++e) { idx.push_back(K_ + sd->v[e]); val.push_back(sd->w[e]); }
-      const double wi = weights_.empty() ? 1.0 : weights_[(size_t)i];   // weighted likelihood: G = [X Z]' W [X Z]
-      for (size_t a = 0; a < idx.size(); ++a) for (size_t b = 0; b < idx.size(); ++b) dense[(size_t)idx[a] * M + idx[b]] += wi * val[a] * val[b];
-    }
+      return weights_.empty() ? 1.0 : weights_[(size_t)i];   // weighted likelihood: G = [X Z]' W [X Z]
+    };
     gramPtr_.assign((size_t)M + 1, 0); gramCol_.clear(); gram_.clear();
-    for (int a = 0; a < M; ++a) {
-      for (int b = 0; b < M; ++b) if (dense[(size_t)a * M + b] != 0.0) { gramCol_.push_back(b); gram_.push_back(dense[(size_t)a * M + b]); }
+    if ((size_t)M * (size_t)M <= ((size_t)1 << 22)) {   // small: a dense scratch matrix (32 MB at most), compressed afterwards
+      std::vector<double> dense((size_t)M * M, 0.0);
+      for (int64_t i = 0; i < sd->N; ++i) {
+        const double wi = row_of(i);
+        for (size_t a = 0; a < idx.size(); ++a) for (size_t b = 0; b < idx.size(); ++b) dense[(size_t)idx[a] * M + idx[b]] += wi * val[a] * val[b];
+      }
+      for (int a = 0; a < M; ++a) {
+        for (int b = 0; b < M; ++b) if (dense[(size_t)a * M + b] != 0.0) { gramCol_.push_back(b); gram_.push_back(dense[(size_t)a * M + b]); }
+        gramPtr_[(size_t)a + 1] = (int)gramCol_.size();
+      }
+      return;
+    }
+    // many groups (e.g. a grouping factor with 1e5 levels): G is never formed densely.  Entries are accumulated per (row, column)
+    // key in a hash map — a row of [X Z] has K + z non-zeros, so the work is N (K + z)^2 and the memory nnz(G)
+    std::unordered_map<uint64_t, double> acc;
+    acc.reserve((size_t)sd->N < ((size_t)1 << 22) ? (size_t)sd->N * 4 : ((size_t)1 << 24));
+    for (int64_t i = 0; i < sd->N; ++i) {
+      const double wi = row_of(i);
+      for (size_t a = 0; a < idx.size(); ++a) for (size_t b = 0; b < idx.size(); ++b) acc[(uint64_t)idx[a] * (uint64_t)M + (uint64_t)idx[b]] += wi * val[a] * val[b];
+    }
+    std::vector<std::pair<uint64_t, double>> ent(acc.begin(), acc.end());
+    std::sort(ent.begin(), ent.end(), [](const std::pair<uint64_t, double>& x, const std::pair<uint64_t, double>& y) { return x.first < y.first; });
+    for (const auto& e : ent) {
+      if (e.second == 0.0) continue;
+      const int a = (int)(e.first / (uint64_t)M);
+      gramCol_.push_back((int)(e.first % (uint64_t)M)); gram_.push_back(e.second);
       gramPtr_[(size_t)a + 1] = (int)gramCol_.size();
     }
+    for (int a = 0; a < M; ++a) if (gramPtr_[(size_t)a + 1] < gramPtr_[(size_t)a]) gramPtr_[(size_t)a + 1] = gramPtr_[(size_t)a];
   }
   // ss = e'We, gX = X'We, gZ = Z'We with e = (y - offset) - X beta - Z b (W = I without weights)
   double likelihood(const double* beta, const double* b, double* gX, double* gZ) {

@@ -407,8 +407,14 @@ def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=N
         results[c] = r
 
     if cores <= 1 or chains == 1:
-        for c in range(chains):            # one stream continued from chain to chain (R/stan4bart_fit.R:545-554)
-            one_chain(c, rng)
+        try:
+            for c in range(chains):        # one stream continued from chain to chain (R/stan4bart_fit.R:545-554)
+                one_chain(c, rng)
+        except Exception:                  # a later chain failed: the kept samplers of the earlier ones hold device memory
+            for sm in samplers:
+                if sm is not None:
+                    sm.free()
+            raise
     else:
         import threading
         seeds = chain_seeds(int(rng.sample_int(INT_MAX, 1)[0]) if seed is None else seed, chains)
