@@ -1,5 +1,6 @@
 """Reads two rocprofv3 --pmc runs (FETCH_SIZE and WRITE_SIZE, separate passes as MI355X_MICROARCH.md prescribes) and
-prints the HBM traffic per launch of the fused tree-update kernel k_tree<true>:
+prints the HBM traffic per launch of the tree-update kernel — k_step (one launch per tree, fused path) or k_tree<true> (two-kernel
+path), whichever the run used:
     bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024
 (the factor 2 is the guide's gfx950 correction: FETCH_SIZE tallies 128-B requests of wide coalesced reads at 64 B).
 Usage: python tools/pmc_traffic.py <fetch.db> <write.db> <n>"""
@@ -14,15 +15,19 @@ def avg(db, counter):
     kcol = "kernel_name" if "kernel_name" in cols else "name"
     sel = "counter_name" if "counter_name" in cols else "pmc_name"
     val = "value" if "value" in cols else "counter_value"
-    row = c.execute(f"select count(*), avg({val}) from pmc_events where {kcol} like '%k_tree<true%' and {sel} = ?", (counter,)).fetchone()
-    return row
+    best = (0, None, None)
+    for pat, label in (("%k_step<%", "k_step"), ("%k_tree<true%", "k_tree<true>")):
+        row = c.execute(f"select count(*), avg({val}) from pmc_events where {kcol} like ? and {sel} = ?", (pat, counter)).fetchone()
+        if row[0] and row[0] > best[0]:
+            best = (row[0], row[1], label)
+    return best
 
 
 if __name__ == "__main__":
-    nf, f = avg(sys.argv[1], "FETCH_SIZE")
-    nw, w = avg(sys.argv[2], "WRITE_SIZE")
+    nf, f, kernel = avg(sys.argv[1], "FETCH_SIZE")
+    nw, w, _ = avg(sys.argv[2], "WRITE_SIZE")
     n = int(sys.argv[3])
-    out = {"n": n, "kernel": "k_tree<true>", "launches": [nf, nw], "FETCH_SIZE_kb": f, "WRITE_SIZE_kb": w,
+    out = {"n": n, "kernel": kernel, "launches": [nf, nw], "FETCH_SIZE_kb": f, "WRITE_SIZE_kb": w,
            "bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0, "algorithmic_bytes": 22.0 * n,
            "correction": "2 x FETCH_SIZE (gfx950: 128-B requests tallied at 64 B) + WRITE_SIZE, KiB -> bytes"}
     print(json.dumps(out))
