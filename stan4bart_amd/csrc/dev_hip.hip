@@ -23,6 +23,11 @@
 #include <string>
 #include <vector>
 
+#ifdef S4B_CONTROL_TIMING
+// (measurement build) birth proposals of candidate wave 1 in workgroup 0: time stamps inside propose()
+__device__ unsigned long long g_prop[32];
+#define S4B_PROP_T(i) do { if (blockIdx.x == 0 && (threadIdx.x >> 6) == 1 && (threadIdx.x & 63) == 0) { atomicAdd(&g_prop[i], (unsigned long long)wall_clock64()); if ((i) == 7) atomicAdd(&g_prop[15], 1ull); if ((i) <= 1) atomicAdd(&g_prop[8 + (i)], 1ull); } } while (0)
+#endif
 #include "sampler_core.hpp"
 
 namespace s4b {
@@ -1809,7 +1814,7 @@ class DevHip {
     // ---- launch configuration
     gridN_ = a.grid;   // one launch geometry for every O(N) kernel: the partial buffers are sized by it
 #ifdef S4B_CONTROL_TIMING
-    { unsigned long long z[24] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_step), z, sizeof(z))); }
+    { unsigned long long z[32] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_step), z, sizeof(z))); }
 #endif
     ldsApply_ = apply_lds_bytes(nc_); ldsTree_ = tree_lds_bytes(nc_); ldsControl_ = control_lds_bytes(P_, d.model.logIntLen);
     if (ldsTree_ > 64 * 1024) {
@@ -2019,12 +2024,20 @@ class DevHip {
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
 #ifdef S4B_CONTROL_TIMING
-    { unsigned long long h[24]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_step), sizeof(h)));
+    { unsigned long long h[32]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_step), sizeof(h)));
+      if (h[27]) fprintf(stderr, "DBG double run: first propose %.2f us, second %.2f us\n", (double)(h[26] - h[24]) / (100.0 * h[0]), (double)(h[27] - h[25]) / (100.0 * h[0]));
       const double k = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0;
+      { unsigned long long q[32]; HIP_OK(hipMemcpyFromSymbol(q, HIP_SYMBOL(g_prop), sizeof(q)));
+        for (int ty = 0; ty < 4; ++ty) fprintf(stderr, "DBG propose type %d: %llu proposals (%llu without a valid move), %.2f us each\n", ty, q[20 + ty], q[24 + ty], q[20 + ty] ? (double)q[16 + ty] / (100.0 * (double)q[20 + ty]) : 0.0);
+        const double c = q[15] ? 1.0 / (100.0 * (double)q[15]) : 0.0;
+        // stamps 0/1 are taken by every proposal, 2..7 by births only: report birth-path deltas from stamp 2 on
+        fprintf(stderr, "DBG propose (births: %llu of %llu): first draw %.2f; select node .. draw var %.2f, interval + split %.2f, build %.2f, child memo %.2f, ratios %.2f us\n", q[15], q[8], q[8] ? (double)(q[1] - q[0]) / (100.0 * (double)q[8]) : 0.0,
+                (double)(q[3] - q[2]) * c, (double)(q[4] - q[3]) * c, (double)(q[5] - q[4]) * c, (double)(q[6] - q[5]) * c, (double)(q[7] - q[6]) * c);
+        unsigned long long z16[32] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_prop), z16, sizeof(z16))); }
       fprintf(stderr, "DBG k_step us from the start of one workgroup (avg over %llu launches): reducers done %.2f | decider loads %.2f totals %.2f verdict posted %.2f decide %.2f stores %.2f | cand0: loads %.2f ready %.2f proposed %.2f verdict %.2f | arrival at the barrier: loaders %.2f cand0 %.2f cand1 %.2f | (iter %.0f) write-backs done %.2f | barrier %.2f pass done %.2f | pass (first bin pass): routing columns arrived +%.2f, prefetched quads done +%.2f (routing init +%.2f, deeper levels +%.2f [%.2f iterations], arithmetic +%.2f), block reduction + partials +%.2f\n",
               h[0], h[1] * k, h[2] * k, h[3] * k, h[23] * k, h[4] * k, h[5] * k, h[19] * k, h[20] * k, h[21] * k, h[22] * k, h[16] * k, h[17] * k, h[18] * k, (double)h[6], h[7] * k, h[8] * k, h[9] * k, (double)(h[11] - h[10]) * k, (double)(h[12] - h[11]) * k, (double)(h[14] - h[11]) * k, (double)(h[15] - h[14]) * k, h[0] ? (double)h[6] / (double)h[0] : 0.0,
               (double)(h[12] - h[15]) * k, (double)(h[13] - h[12]) * k);
-      unsigned long long z[24] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_step), z, sizeof(z))); }
+      unsigned long long z[32] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_step), z, sizeof(z))); }
 #endif
     out[0] = cnt ? sum / cnt : 0.0; out[3] = cnt;        // the fused launch (statistics + control + apply)
     out[1] = 0.0; out[4] = 0.0;                          // no separate control kernel

@@ -452,6 +452,9 @@ S4B_HD inline bool tv_subtree_pass(const TR& cur, TR& pt, const MV& m, int nd, b
   return true;
 }
 
+#ifndef S4B_PROP_T
+#define S4B_PROP_T(i)
+#endif
 // ------------------------------------------------------------------ propose
 // Fills `pr` and the tables for the next update of tree `cur` (hwm = slots in use).  Preconditions: the
 // structure cache `ca` of `cur` is valid (tv_rebuild_cache), the proposed tree is a copy of `cur` (memo
@@ -465,7 +468,9 @@ S4B_HD inline int propose(const TR& cur, int hwm, const MV& m, RNG* rng, Proposa
   pr->nbA = nl; pr->nbB = 0; pr->hwm = hwm; pr->node = 0; pr->var = -1; pr->split = -1; pr->status = -1;
   pr->newLeft = pr->newRight = -1; pr->priorRatio = pr->transRatio = 1.0; pr->XLogPi = pr->YLogPi = 0.0;
 
+  S4B_PROP_T(0);
   double u = r_unif(rng);
+  S4B_PROP_T(1);
   if (u < m.pBD) {
     const bool single = ni == 0;
     const int g = single ? 1 : ca.g;   // leaves that can still grow
@@ -479,11 +484,14 @@ S4B_HD inline int propose(const TR& cur, int hwm, const MV& m, RNG* rng, Proposa
         for (int i = 0; i < nl; ++i) { int lf = ca.leaf.get(i); if (tv_num_avail(cur, m, lf) > 0) { if (idx == 0) { nd = lf; break; } --idx; } }
         pSelect = 1.0 / (double)g;
       }
+      S4B_PROP_T(2);
       int depthNd = tv_depth_of(cur, nd);
       double pgParent = mv_pg_depth(m, depthNd);      // nd is growable: numAvail > 0
       int v = tv_draw_var(cur, m, nd, rng);
+      S4B_PROP_T(3);
       int lo, hi; tv_interval(cur, m, nd, v, lo, hi);
       int s = r_unif_int(rng, lo, hi + 1);
+      S4B_PROP_T(4);
       int h2 = hwm;
       int L = tv_alloc(pt, h2); if (L < 0) return -1;
       pt.var.set(L, NODE_LEAF);
@@ -492,8 +500,10 @@ S4B_HD inline int propose(const TR& cur, int hwm, const MV& m, RNG* rng, Proposa
       pt.var.set(L, NODE_LEAF); pt.left.set(L, -1); pt.right.set(L, -1); pt.parent.set(L, (int16_t)nd); pt.cut.set(L, 0);
       pt.var.set(R, NODE_LEAF); pt.left.set(R, -1); pt.right.set(R, -1); pt.parent.set(R, (int16_t)nd); pt.cut.set(R, 0);
       for (int i = hwm; i < h2; ++i) { tb.binA.set(i, -1); tb.binB.set(i, -1); tb.insub.set(i, 0); }
+      S4B_PROP_T(5);
       double pgChild = mv_pg_depth(m, depthNd + 1);
       tv_fill_info_node(pt, m, L); tv_fill_info_node(pt, m, R);
+      S4B_PROP_T(6);
       int naL = tv_num_avail(pt, m, L), naR = tv_num_avail(pt, m, R);
       double pgL = naL == 0 ? 0.0 : pgChild, pgR = naR == 0 ? 0.0 : pgChild;
       double newPrior = pgParent * (1.0 - pgL) * (1.0 - pgR);
@@ -510,6 +520,7 @@ S4B_HD inline int propose(const TR& cur, int hwm, const MV& m, RNG* rng, Proposa
       pr->node = nd; pr->var = v; pr->split = s; pr->newLeft = L; pr->newRight = R; pr->hwm = h2;
       tb.insub.set(nd, 1); tb.binB.set(L, (int16_t)nl); tb.binB.set(R, (int16_t)(nl + 1)); pr->nbB = 2;
       pr->status = 1;
+      S4B_PROP_T(7);
     } else {
       pr->type = MOVE_DEATH;
       const int gn = ca.gn;
