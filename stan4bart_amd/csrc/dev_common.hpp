@@ -33,6 +33,9 @@ struct StepScratch {
   // writes the updated tree to the main arrays, so no workgroup ever reads what another one writes in the same launch
   StepHeader* head; double* snapMu; int32_t* snapCnt;
 };
+// image of a proposal drawn one launch ahead: everything a scratch set holds for the step (same slab rows), the generator state
+// the proposal leaves behind, and meta = {valid, draws the decide step before it was assumed to consume, propose() error code}
+struct CandSet { int16_t* slab; uint8_t* insub; StepHeader* head; double* snapMu; int32_t* snapCnt; MTState* rng; int32_t* meta; };
 // row order of the slabs (the individual pointers are views into them)
 enum { SF_VAR = 0, SF_CUT, SF_LEFT, SF_RIGHT, SF_PARENT, SF_NA, SF_DEP, SF_BINA, SF_BINB,
        SF_CVAR, SF_CCUT, SF_CLEFT, SF_CRIGHT, SF_CPARENT, SF_CNA, SF_CDEP, SF_CLEAF, SF_CPRE, SF_CPOST, SF_COUNT };
@@ -76,6 +79,9 @@ struct BartArrays {
   // rngF[2] (rng == &rngF[0] between sweeps); preDone[s] = the control step of the launch with parity s was already run
   // by the tail of the previous launch (trees too large for the wave-register path); ticket counts finished workgroups
   double* partF; int32_t gridF; MTState* rngF; int32_t* preDone; int32_t* ticket;
+  // proposals drawn one launch ahead (fused path): candBase + (2 * parity + c) * candStride is the image of candidate c for the
+  // tree with that parity of index, layout in cand_view(); the control workgroup of launch t-1 writes the two images for tree t
+  unsigned char* candBase; int64_t candStride;
   MTState* rng; ScaleState* scale; const int32_t* numCuts;
   StepRecord* trace; int32_t* traceCount; int32_t* errFlag;
   ModelView model;             // numCuts inside points to device memory

@@ -1753,9 +1753,12 @@ class DevHip {
     a.rngF = zalloc<MTState>(2); a.rng = a.rngF; a.scale = zalloc<ScaleState>(1);
     a.preDone = zalloc<int32_t>(2); a.ticket = zalloc<int32_t>(1);
     {   // fused path (one launch per tree update, dev_step.inc): one 512-thread workgroup per CU at most
-      a.gridF = (int)std::min<int64_t>(256, std::max<int64_t>(1, (nQuads + F_PT - 1) / F_PT));
-      if (const char* g = getenv("S4B_GRIDF")) { int v = atoi(g); if (v >= 1 && v <= F_GRID_MAX) a.gridF = v; }
-      const int64_t perThread = (nQuads + (int64_t)a.gridF * F_PT - 1) / ((int64_t)a.gridF * F_PT);
+      // gridF - 1 workgroups share the observations, the last one is the control workgroup (write-backs, proposals one launch ahead)
+      a.gridF = 1 + (int)std::min<int64_t>(255, std::max<int64_t>(1, (nQuads + F_PT - 1) / F_PT));
+      if (const char* g = getenv("S4B_GRIDF")) { int v = atoi(g); if (v >= 2 && v <= F_GRID_MAX) a.gridF = v; }
+      const int64_t passThreads = (int64_t)(a.gridF - 1) * F_PT;
+      const int64_t perThread = (nQuads + passThreads - 1) / passThreads;
+      a.candStride = (int64_t)cand_bytes(nc_); a.candBase = zalloc<unsigned char>((size_t)4 * cand_bytes(nc_));
       ldsStep_ = step_lds_bytes(nc_, d.weights != nullptr);
       // automatic choice: the fused launch wins while a tree update is latency-bound; at large n the two-kernel path keeps
       // more waves streaming (4 per SIMD instead of 2)
@@ -2025,7 +2028,6 @@ class DevHip {
     for (auto& e : ev) (void)hipEventDestroy(e);
 #ifdef S4B_CONTROL_TIMING
     { unsigned long long h[32]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_step), sizeof(h)));
-      if (h[27]) fprintf(stderr, "DBG double run: first propose %.2f us, second %.2f us\n", (double)(h[26] - h[24]) / (100.0 * h[0]), (double)(h[27] - h[25]) / (100.0 * h[0]));
       const double k = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0;
       { unsigned long long q[32]; HIP_OK(hipMemcpyFromSymbol(q, HIP_SYMBOL(g_prop), sizeof(q)));
         for (int ty = 0; ty < 4; ++ty) fprintf(stderr, "DBG propose type %d: %llu proposals (%llu without a valid move), %.2f us each\n", ty, q[20 + ty], q[24 + ty], q[20 + ty] ? (double)q[16 + ty] / (100.0 * (double)q[20 + ty]) : 0.0);
@@ -2034,6 +2036,17 @@ class DevHip {
         fprintf(stderr, "DBG propose (births: %llu of %llu): first draw %.2f; select node .. draw var %.2f, interval + split %.2f, build %.2f, child memo %.2f, ratios %.2f us\n", q[15], q[8], q[8] ? (double)(q[1] - q[0]) / (100.0 * (double)q[8]) : 0.0,
                 (double)(q[3] - q[2]) * c, (double)(q[4] - q[3]) * c, (double)(q[5] - q[4]) * c, (double)(q[6] - q[5]) * c, (double)(q[7] - q[6]) * c);
         unsigned long long z16[32] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_prop), z16, sizeof(z16))); }
+      { static unsigned long long ws[F_GRID_MAX], we[F_GRID_MAX];
+        HIP_OK(hipMemcpyFromSymbol(ws, HIP_SYMBOL(g_wgS), sizeof(ws))); HIP_OK(hipMemcpyFromSymbol(we, HIP_SYMBOL(g_wgE), sizeof(we)));
+        const int G = a_.gridF; unsigned long long s0 = ~0ull; for (int b = 0; b < G; ++b) if (ws[b] < s0) s0 = ws[b];
+        double lastEnd = 0, lastStart = 0; int bEnd = 0, bStart = 0;
+        for (int b = 0; b < G; ++b) { const double st = (double)(ws[b] - s0) * k, en = (double)(we[b] - s0) * k; if (en > lastEnd) { lastEnd = en; bEnd = b; } if (st > lastStart) { lastStart = st; bStart = b; } }
+        fprintf(stderr, "DBG workgroups (average us after the earliest start): last start %.2f (block %d), last end %.2f (block %d); ends of blocks 0, G/2, G-2, G-1: %.2f %.2f %.2f %.2f; starts: %.2f %.2f %.2f %.2f\n",
+                lastStart, bStart, lastEnd, bEnd, (double)(we[0] - s0) * k, (double)(we[G / 2] - s0) * k, (double)(we[G - 2] - s0) * k, (double)(we[G - 1] - s0) * k,
+                (double)(ws[0] - s0) * k, (double)(ws[G / 2] - s0) * k, (double)(ws[G - 2] - s0) * k, (double)(ws[G - 1] - s0) * k);
+        memset(ws, 0, sizeof(ws)); HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_wgS), ws, sizeof(ws))); HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_wgE), ws, sizeof(ws))); }
+      fprintf(stderr, "DBG control workgroup (us from its start): proposal settled %.2f, draw ahead starts %.2f, drawn %.2f, image written %.2f | launches with both halves %llu, of which wave 0 had to propose itself %llu | wave 0 enters its role %.2f, all loads issued %.2f\n",
+              h[24] * k, h[25] * k, h[26] * k, h[27] * k, h[29], h[28], h[30] * k, h[31] * k);
       fprintf(stderr, "DBG k_step us from the start of one workgroup (avg over %llu launches): reducers done %.2f | decider loads %.2f totals %.2f verdict posted %.2f decide %.2f stores %.2f | cand0: loads %.2f ready %.2f proposed %.2f verdict %.2f | arrival at the barrier: loaders %.2f cand0 %.2f cand1 %.2f | (iter %.0f) write-backs done %.2f | barrier %.2f pass done %.2f | pass (first bin pass): routing columns arrived +%.2f, prefetched quads done +%.2f (routing init +%.2f, deeper levels +%.2f [%.2f iterations], arithmetic +%.2f), block reduction + partials +%.2f\n",
               h[0], h[1] * k, h[2] * k, h[3] * k, h[23] * k, h[4] * k, h[5] * k, h[19] * k, h[20] * k, h[21] * k, h[22] * k, h[16] * k, h[17] * k, h[18] * k, (double)h[6], h[7] * k, h[8] * k, h[9] * k, (double)(h[11] - h[10]) * k, (double)(h[12] - h[11]) * k, (double)(h[14] - h[11]) * k, (double)(h[15] - h[14]) * k, h[0] ? (double)h[6] / (double)h[0] : 0.0,
               (double)(h[12] - h[15]) * k, (double)(h[13] - h[12]) * k);
