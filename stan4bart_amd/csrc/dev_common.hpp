@@ -21,17 +21,19 @@ enum : int32_t { S4B_ERR_NODE_CAPACITY = 1, S4B_ERR_TRACE_OVERFLOW = 2, S4B_ERR_
 // header of one scratch set: the pending proposal of the set's tree and (fused path) the scalars of the tree's snapshot
 struct StepHeader { Proposal pr; int32_t hwm, nl, ni, g, gn, valid; double logPi; };
 
+// (field order: what the fused launch fetches first comes first, so that its kernel-argument words share few cache lines)
 struct StepScratch {
-  int16_t *pvar, *pleft, *pright, *pparent; uint16_t* pcut;
-  int16_t *binA, *binB, *list; uint8_t* insub;
-  double* muOld; Proposal* prop; int32_t* accepted;
-  int16_t *pna, *pdep;                // node memo of the proposed tree (pointer path)
-  double* work;                       // [7][2 nc] decide() work arrays (pointer path)
-  int16_t* slab;                      // device: the nine int16 tables above are rows of one [SF_COUNT][nc] slab (one base address)
+  int16_t* slab;                      // device: the int16 tables below are rows of one [SF_COUNT][nc] slab (one base address)
+  uint8_t* insub;
   // fused path (one launch per tree update): the launch that proposes for tree t also snapshots tree t (rows SF_C* of the
-  // slab, leaf values, node sizes, header scalars); the next launch decides from the snapshot while its first workgroup
+  // slab, leaf values, node sizes, header scalars); the next launch decides from the snapshot while the control workgroup
   // writes the updated tree to the main arrays, so no workgroup ever reads what another one writes in the same launch
   StepHeader* head; double* snapMu; int32_t* snapCnt;
+  int32_t* accepted; double* muOld; Proposal* prop;
+  int16_t *pvar, *pleft, *pright, *pparent; uint16_t* pcut;
+  int16_t *binA, *binB, *list;
+  int16_t *pna, *pdep;                // node memo of the proposed tree (pointer path)
+  double* work;                       // [7][2 nc] decide() work arrays (pointer path)
 };
 // image of a proposal drawn one launch ahead: everything a scratch set holds for the step (same slab rows), the generator state
 // the proposal leaves behind, and meta = {valid, draws the decide step before it was assumed to consume, propose() error code}
@@ -43,49 +45,53 @@ enum { TF_VAR = 0, TF_CUT, TF_LEFT, TF_RIGHT, TF_PARENT, TF_NA, TF_DEP, TF_LEAF,
 enum { TI_HWM = 0, TI_NL, TI_NI, TI_G, TI_GN, TI_VALID, TI_COUNT };
 
 // device-resident state of one chain's BART block (all pointers are device pointers)
+// (field order: the words the fused launch (dev_step.inc) needs before its first memory hop are the first ~5 cache lines of the
+// kernel-argument block; a wave fetches argument words lazily, one dependent fetch per cache line it has not touched yet)
 struct BartArrays {
   int64_t n, npad;             // observations, padded column stride (multiple of 8)
   int32_t P, T, nc;            // predictors, trees, node slots per tree
   int32_t grid;                // workgroups of the O(N) kernels (fixed => deterministic reductions)
   int32_t binCap;              // bins per tree update (<= 2 nc)
+  int32_t gridF;               // workgroups of the fused launch (the last one is the control workgroup)
+  int32_t binary, traceOn;
+  double* R;                   // [n]  yRescaled - sum of tree fits (the shared residual)
+  uint16_t* leaf;              // [T][npad] node id of the leaf holding observation i in tree t
+  const double* wts;                  // [n] observation weights or null (dbarts data@weights, Stan has_weights)
+  const uint16_t* xbin;        // [P][npad]   binned predictors, one column contiguous
+  // fused path: partials double-buffered by step parity, [2][3 (sum, count, weight)][binCap][gridF]; generator slots
+  // rngF[2] (rng == &rngF[0] between sweeps); preDone[s] = the control step of the launch with parity s was already run
+  // by the tail of the previous launch (trees too large for the wave-register path); ticket counts finished workgroups
+  double* partF; int32_t* preDone; MTState* rngF;
+  // proposals drawn one launch ahead (fused path): candBase + (2 * parity + c) * candStride is the image of candidate c for the
+  // tree with that parity of index, layout in cand_view(); the control workgroup of launch t-1 writes the two images for tree t
+  unsigned char* candBase; int64_t candStride;
+  // device: the int16 per-node arrays are rows of treeI16[TF_COUNT][T nc], the int32 per-tree scalars rows of treeI32[TI_COUNT][T]
+  // (the control kernel addresses them from these two bases instead of fetching sixteen kernel-argument pointers)
+  int16_t* treeI16; int32_t* treeI32;
+  double* mu; int32_t* cnt; double* clogpi;   // trees [T][nc]: leaf values, node sizes; [T] log tree prior
+  ScaleState* scale; const int32_t* numCuts; int32_t* errFlag; int32_t* ticket;
+  ModelView model;             // numCuts inside points to device memory
+  // updates in flight: two scratch sets, tree t uses set (t & 1) so that the proposal of tree t+1 can be
+  // drawn (same lane, same RNG stream position) while the apply pass of tree t still reads its tables
+  StepScratch sc[2];
   int32_t traceCap;
   int64_t nTest, nTestPad;
-  const uint16_t* xbin;        // [P][npad]   binned predictors, one column contiguous
   const uint16_t* xbinTest;    // [P][nTestPad]
   const double* y;             // [n]
-  double* R;                   // [n]  yRescaled - sum of tree fits (the shared residual)
   double* off;                 // [n]  current BART offset (parametric mean [+ user offset])
   double* offNew;              // [n]  next offset
   const double* userOffset;    // [n] or null
   double* lat;                 // [n] probit only: latent response with the offset removed (dbarts probitLatents)
-  int32_t binary;
-  uint16_t* leaf;              // [T][npad] node id of the leaf holding observation i in tree t
   // trees, [T][nc]
-  int16_t *var, *left, *right, *parent; uint16_t* cut; double* mu; int32_t* cnt; int32_t* hwm;
+  int16_t *var, *left, *right, *parent; uint16_t* cut; int32_t* hwm;
   // per-tree structure cache, [T][nc] / [T]: node memo (available predictors, depth), leaves in DFS order,
   // internal nodes in pre- and post-order, log tree prior; rebuilt lazily after an accepted move
-  int16_t *cna, *cdep, *cleaf, *cpre, *cpost; int32_t *cnl, *cni, *cg, *cgn, *cvalid; double* clogpi;
-  // device: the int16 per-node arrays are rows of treeI16[TF_COUNT][T nc], the int32 per-tree scalars rows of treeI32[TI_COUNT][T]
-  // (the control kernel addresses them from these two bases instead of fetching sixteen kernel-argument pointers)
-  int16_t* treeI16; int32_t* treeI32;
-  // updates in flight: two scratch sets, tree t uses set (t & 1) so that the proposal of tree t+1 can be
-  // drawn (same lane, same RNG stream position) while the apply pass of tree t still reads its tables
-  StepScratch sc[2];
+  int16_t *cna, *cdep, *cleaf, *cpre, *cpost; int32_t *cnl, *cni, *cg, *cgn, *cvalid;
   double* partCnt; double* partSum;   // [binCap][grid] per-workgroup partials
   double* binCnt; double* binSum;     // [binCap]
-  const double* wts;                  // [n] observation weights or null (dbarts data@weights, Stan has_weights)
   double* partWt; double* binWt;      // weight totals per bin, only with weights
-  // fused path: partials double-buffered by step parity, [2][3 (sum, count, weight)][binCap][gridF]; generator slots
-  // rngF[2] (rng == &rngF[0] between sweeps); preDone[s] = the control step of the launch with parity s was already run
-  // by the tail of the previous launch (trees too large for the wave-register path); ticket counts finished workgroups
-  double* partF; int32_t gridF; MTState* rngF; int32_t* preDone; int32_t* ticket;
-  // proposals drawn one launch ahead (fused path): candBase + (2 * parity + c) * candStride is the image of candidate c for the
-  // tree with that parity of index, layout in cand_view(); the control workgroup of launch t-1 writes the two images for tree t
-  unsigned char* candBase; int64_t candStride;
-  MTState* rng; ScaleState* scale; const int32_t* numCuts;
-  StepRecord* trace; int32_t* traceCount; int32_t* errFlag;
-  ModelView model;             // numCuts inside points to device memory
-  int32_t traceOn;
+  MTState* rng;
+  StepRecord* trace; int32_t* traceCount;
 };
 
 S4B_HD inline TreeView tree_view(const BartArrays& a, int t) {

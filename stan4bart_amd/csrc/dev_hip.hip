@@ -28,6 +28,10 @@
 __device__ unsigned long long g_prop[32];
 #define S4B_PROP_T(i) do { if (blockIdx.x == 0 && (threadIdx.x >> 6) == 1 && (threadIdx.x & 63) == 0) { atomicAdd(&g_prop[i], (unsigned long long)wall_clock64()); if ((i) == 7) atomicAdd(&g_prop[15], 1ull); if ((i) <= 1) atomicAdd(&g_prop[8 + (i)], 1ull); } } while (0)
 #endif
+#ifdef S4B_CONTROL_TIMING
+__device__ unsigned long long g_dec[16];
+#define S4B_DEC_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&g_dec[i], (unsigned long long)wall_clock64()); if ((i) == 0) atomicAdd(&g_dec[15], 1ull); } } while (0)
+#endif
 #include "sampler_core.hpp"
 
 namespace s4b {
@@ -416,6 +420,45 @@ __device__ __forceinline__ uint32_t mt_next(WaveRng* r) {
   y ^= (y << 15) & 0xefc60000u;
   y ^= (y >> 18);
   return y;
+}
+
+// lane-parallel leaf statistics + draws of decide(): lane i owns leaf i of the cached DFS list.  The uniforms are the generator's
+// next words in leaf order (two per leaf that holds observations): lane i reads the pair at its rank among those leaves.
+__device__ __forceinline__ int wave_gather(int idx, int v) { return __builtin_amdgcn_ds_bpermute(idx << 2, v); }
+__device__ __forceinline__ double wave_gather(int idx, const WaveArrD& a) { return __hiloint2double(wave_gather(idx, a.hi), wave_gather(idx, a.lo)); }
+__device__ __forceinline__ double mt_word_to_unif(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  const double half_ulp = 0.5 * 2.328306437080797e-10;
+  const double v = (double)y * 2.3283064365386963e-10;
+  return v <= 0.0 ? half_ulp : (1.0 - v <= 0.0 ? 1.0 - half_ulp : v);
+}
+__device__ __forceinline__ void leaf_stats_draws(const WaveTables& tb, const WaveCache& ca, const WaveArrD& binCnt, const WaveArrD& binSum, const WaveArrD& binWt,
+                                                 bool acc, bool deathAcc, int nd, double cDeath, double sDeath, double wDeath, DecideWork<WaveArrD>& wk, WaveRng* rng) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int nl = ca.nl;
+  const bool in = lane < nl;
+  const int n = in ? ca.leaf.r : 0;
+  const int bB = (int)(int16_t)wave_gather(n, tb.binB.r), bA = (int)(int16_t)wave_gather(n, tb.binA.r);
+  const int b = ((acc && !deathAcc && bB >= 0) ? bB : bA) & 63;
+  double lc = wave_gather(b, binCnt), ls = wave_gather(b, binSum), lw = wave_gather(b, binWt);
+  const bool dn = deathAcc && n == nd;
+  lc = dn ? cDeath : lc; ls = dn ? sDeath : ls; lw = dn ? wDeath : lw;
+  const bool ne = in && lc != 0.0;
+  const unsigned long long mask = __ballot(ne);
+  const int cnt = __popcll(mask);
+  if (rng->mti + 2 * cnt > 624) {   // the block of words runs out among these draws (about one step in a hundred): one draw at a time
+    leaf_stats_draws<WaveTables, WaveCache, WaveArrD, WaveArrD, WaveRng>(tb, ca, binCnt, binSum, binWt, acc, deathAcc, nd, cDeath, sDeath, wDeath, wk, rng);
+    return;
+  }
+  const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+  const int k = ne ? rng->mti + 2 * rank : 0;
+  const uint32_t y1 = rng->st->mt[k], y2 = rng->st->mt[k + 1];
+  if (in) { wk.lc.load(lc); wk.ls.load(ls); wk.lw.load(lw); }
+  if (ne) { wk.u1.load(mt_word_to_unif(y1)); wk.u2.load(mt_word_to_unif(y2)); }
+  rng->mti += 2 * cnt; rng->count += 2 * cnt; rng->wbase = -64;
 }
 
 // Model view of the control wave: the prior tables sit in registers (lane d / lane k), LDS only beyond 64 / 128
@@ -2045,6 +2088,12 @@ class DevHip {
                 lastStart, bStart, lastEnd, bEnd, (double)(we[0] - s0) * k, (double)(we[G / 2] - s0) * k, (double)(we[G - 2] - s0) * k, (double)(we[G - 1] - s0) * k,
                 (double)(ws[0] - s0) * k, (double)(ws[G / 2] - s0) * k, (double)(ws[G - 2] - s0) * k, (double)(ws[G - 1] - s0) * k);
         memset(ws, 0, sizeof(ws)); HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_wgS), ws, sizeof(ws))); HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_wgE), ws, sizeof(ws))); }
+      { unsigned long long q[16]; HIP_OK(hipMemcpyFromSymbol(q, HIP_SYMBOL(g_dec), sizeof(q)));
+        const double c = q[15] ? 1.0 / (100.0 * (double)q[15]) : 0.0;
+        // (stamps 1, 2 are only taken for valid proposals: their deltas are approximate)
+        fprintf(stderr, "DBG decide (%llu): stamps 0..7 deltas: total %.2f | leaf loop (draws) %.2f, quantiles %.2f, write-out %.2f | entry->accept test done %.2f, accepted-tree update %.2f\n", q[15],
+                (double)(q[7] - q[0]) * c, (double)(q[5] - q[4]) * c, (double)(q[6] - q[5]) * c, (double)(q[7] - q[6]) * c, (double)(q[3] - q[0]) * c, (double)(q[4] - q[3]) * c);
+        unsigned long long z16[16] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_dec), z16, sizeof(z16))); }
       fprintf(stderr, "DBG control workgroup (us from its start): proposal settled %.2f, draw ahead starts %.2f, drawn %.2f, image written %.2f | launches with both halves %llu, of which wave 0 had to propose itself %llu | wave 0 enters its role %.2f, all loads issued %.2f\n",
               h[24] * k, h[25] * k, h[26] * k, h[27] * k, h[29], h[28], h[30] * k, h[31] * k);
       fprintf(stderr, "DBG k_step us from the start of one workgroup (avg over %llu launches): reducers done %.2f | decider loads %.2f totals %.2f verdict posted %.2f decide %.2f stores %.2f | cand0: loads %.2f ready %.2f proposed %.2f verdict %.2f | arrival at the barrier: loaders %.2f cand0 %.2f cand1 %.2f | (iter %.0f) write-backs done %.2f | barrier %.2f pass done %.2f | pass (first bin pass): routing columns arrived +%.2f, prefetched quads done +%.2f (routing init +%.2f, deeper levels +%.2f [%.2f iterations], arithmetic +%.2f), block reduction + partials +%.2f\n",

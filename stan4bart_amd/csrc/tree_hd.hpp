@@ -455,6 +455,9 @@ S4B_HD inline bool tv_subtree_pass(const TR& cur, TR& pt, const MV& m, int nd, b
 #ifndef S4B_PROP_T
 #define S4B_PROP_T(i)
 #endif
+#ifndef S4B_DEC_T
+#define S4B_DEC_T(i)
+#endif
 // ------------------------------------------------------------------ propose
 // Fills `pr` and the tables for the next update of tree `cur` (hwm = slots in use).  Preconditions: the
 // structure cache `ca` of `cur` is valid (tv_rebuild_cache), the proposed tree is a copy of `cur` (memo
@@ -657,22 +660,44 @@ S4B_HD inline void leaves_draw(const AF64& lc, const AF64& ls, const AF64& lw, c
 template <class AF64>
 struct DecideWork { AF64 ll, lc, ls, u1, u2, val, lw; };
 
+// statistics of every leaf of the tree decide() ends with, in the cached DFS order, and the two uniforms of each leaf draw,
+// consumed in that order (a leaf without observations draws nothing)
+template <class TBL, class CA, class ABIN, class AF64, class RNG>
+S4B_HD inline void leaf_stats_draws(const TBL& tb, const CA& ca, const ABIN& binCnt, const ABIN& binSum, const ABIN& binWt, bool acc, bool deathAcc, int nd,
+                                    double cDeath, double sDeath, double wDeath, DecideWork<AF64>& wk, RNG* rng) {
+  const int nl = ca.nl;
+  for (int i = 0; i < nl; ++i) {
+    int n = ca.leaf.get(i);
+    double lc, ls, lw;
+    if (deathAcc && n == nd) { lc = cDeath; ls = sDeath; lw = wDeath; }
+    else {
+      int bB = tb.binB.get(n);
+      int b = (acc && !deathAcc && bB >= 0) ? bB : (int)tb.binA.get(n);
+      lc = binCnt.get(b); ls = binSum.get(b); lw = binWt.get(b);
+    }
+    wk.lc.set(i, lc); wk.ls.set(i, ls); wk.lw.set(i, lw);
+    if (lc != 0.0) { wk.u1.set(i, r_unif(rng)); wk.u2.set(i, r_unif(rng)); }
+  }
+}
+
 struct NoHook { S4B_HD void operator()() const {} };
 // `drawsDone` is called once the last random number of the step has been consumed (before the batched leaf arithmetic)
 template <class TR, class TBL, class AF64, class AI32, class ABIN, class CA, class MV, class RNG, class HOOK = NoHook>
 S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, const MV& m, double sigma, RNG* rng,
                          const Proposal* pr, TBL& tb, const ABIN& binCnt, const ABIN& binSum, const ABIN& binWt, DecideWork<AF64>& wk,
-                         int32_t* accepted, StepRecord* rec, CA& ca, const HOOK& drawsDone = HOOK()) {
+                         int32_t* accepted, StepRecord* rec, CA& ca, const HOOK& drawsDone = HOOK(), bool keepCache = true) {
   TR& pt = tb.prop;
   sigma = S4B_UNI(sigma);
   const double sigma2 = sigma * sigma;
   int acc = 0;
   const int prHwm = S4B_UNI(pr->hwm), prType = S4B_UNI(pr->type), prStatus = S4B_UNI(pr->status), prNode = S4B_UNI(pr->node);
+  S4B_DEC_T(0);
   copy_leaf_values(mu, muOld, hwm, prHwm);
   const int nbAll = S4B_UNI(pr->nbA) + S4B_UNI(pr->nbB);
   if (prStatus == 1) {
     const int nd = prNode;
     bins_loglik(binCnt, binSum, binWt, nbAll, sigma2, m.leafPrec, wk.ll);
+    S4B_DEC_T(1);
     double oldLL = 0.0, newLL = 0.0; bool oldEmpty = false, newEmpty = false;
     if (prType == MOVE_BIRTH) {          // old branch = the leaf itself, new branch = its two children (left, right)
       int b0 = tb.binA.get(nd);
@@ -702,8 +727,10 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
     double ratio;
     if (prType == MOVE_BIRTH || prType == MOVE_DEATH) ratio = S4B_UNI(pr->priorRatio) * exp(newLL - oldLL) * S4B_UNI(pr->transRatio);
     else ratio = exp(S4B_UNI(pr->YLogPi) + newLL - S4B_UNI(pr->XLogPi) - oldLL);
+    S4B_DEC_T(2);
     acc = (r_unif(rng) < S4B_UNI(ratio)) ? 1 : 0;
   }
+  S4B_DEC_T(3);
   // sufficient statistics of every leaf of the tree we end up with, in DFS order; the uniforms of the leaf
   // draws are consumed in that order, the (expensive) quantile / posterior arithmetic is batched afterwards
   const bool deathAcc = acc && prType == MOVE_DEATH;
@@ -719,9 +746,12 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
     // keep the structure cache in step with the accepted move instead of rebuilding it from scratch:
     //   swap / change: same shape, the memo of the subtree was filled for the proposal, log prior = YLogPi
     //   birth / death: three own terms of the log prior change; the node lists are re-walked once
+    // (keepCache = false: the caller throws the cache away — only the leaf list, which orders the draws below, is kept current)
     if (prType == MOVE_SWAP || prType == MOVE_CHANGE) {
       tv_copy(pt, cur, prHwm); hwm = prHwm;
       ca.logPi = S4B_UNI(pr->YLogPi);
+    } else if (!keepCache) {
+      tv_copy(pt, cur, prHwm); hwm = prHwm;
     } else if (prType == MOVE_BIRTH) {
       const int depthNd = tv_depth_of(cur, nd);
       const double before = tv_log_prior_own(cur, m, nd, depthNd);
@@ -745,27 +775,20 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
       }
       ca.nl = nlw; ca.ni = np;
     }
-    tv_recount(cur, m, ca);
+    if (keepCache) tv_recount(cur, m, ca);
   }
+  S4B_DEC_T(4);
   // DFS leaf list of the tree we end up with (the cache is current either way)
   const int nl = ca.nl;
-  for (int i = 0; i < nl; ++i) {
-    int n = ca.leaf.get(i);
-    double lc, ls, lw;
-    if (deathAcc && n == nd) { lc = cDeath; ls = sDeath; lw = wDeath; }
-    else {
-      int bB = tb.binB.get(n);
-      int b = (acc && !deathAcc && bB >= 0) ? bB : (int)tb.binA.get(n);
-      lc = binCnt.get(b); ls = binSum.get(b); lw = binWt.get(b);
-    }
-    wk.lc.set(i, lc); wk.ls.set(i, ls); wk.lw.set(i, lw);
-    if (lc != 0.0) { wk.u1.set(i, r_unif(rng)); wk.u2.set(i, r_unif(rng)); }
-  }
+  leaf_stats_draws(tb, ca, binCnt, binSum, binWt, acc != 0, deathAcc, nd, cDeath, sDeath, wDeath, wk, rng);
+  S4B_DEC_T(5);
   drawsDone();
   leaves_draw(wk.lc, wk.ls, wk.lw, wk.u1, wk.u2, nl, sigma2, m.leafPrec, wk.val);
+  S4B_DEC_T(6);
   for (int i = 0; i < nl; ++i) { int n = ca.leaf.get(i); cnt.set(n, (int32_t)wk.lc.get(i)); mu.set(n, wk.val.get(i)); }
   if (rec) { rec->type = prType; rec->status = prStatus == 1 ? acc : -1; rec->var = pr->var; rec->split = pr->split; rec->numLeaves = nl; }
   *accepted = acc;
+  S4B_DEC_T(7);
   return hwm;
 }
 
