@@ -2101,6 +2101,13 @@ class DevHip {
               (double)(h[12] - h[15]) * k, (double)(h[13] - h[12]) * k);
       unsigned long long z[32] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_step), z, sizeof(z))); }
 #endif
+#ifdef S4B_LIGHT_TIMING
+    { unsigned long long h[16]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_arr), sizeof(h)));
+      const double k = h[9] ? 1.0 / (100.0 * (double)h[9]) : 0.0;
+      fprintf(stderr, "LIGHT k_step, workgroup 100, us from its start (avg over %llu launches): arrival at the barrier of waves 0..7: %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f | pass done %.2f\n",
+              h[9], h[0] * k, h[1] * k, h[2] * k, h[3] * k, h[4] * k, h[5] * k, h[6] * k, h[7] * k, h[8] * k);
+      unsigned long long z[16] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_arr), z, sizeof(z))); }
+#endif
     out[0] = cnt ? sum / cnt : 0.0; out[3] = cnt;        // the fused launch (statistics + control + apply)
     out[1] = 0.0; out[4] = 0.0;                          // no separate control kernel
     out[2] = cntLast ? sumLast / cntLast : 0.0; out[5] = cntLast;
