@@ -49,9 +49,32 @@ constexpr int NBMAX = 16;           // bins accumulated in registers per pass
 
 // ------------------------------------------------------------------------------------------------
 // wave / block reductions with a fixed order (deterministic)
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// value of lane (l ^ O), O a power of two: register-to-register on gfx950 (DPP within rows of 16 lanes, the permlane swaps across
+// them) instead of a trip through the LDS crossbar (ds_bpermute) — the dependent exchange chains of the reductions are several
+// times shorter
+template <int O>
+__device__ __forceinline__ int wave_xor(int v) {
+  static_assert(O == 1 || O == 2 || O == 4 || O == 8 || O == 16 || O == 32, "power of two below 64");
+  if constexpr (O == 1) return __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false);           // quad_perm [1,0,3,2]
+  else if constexpr (O == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+  else if constexpr (O == 4) {   // lanes with bit 2 clear read lane + 4 (row_shl:4), the others lane - 4 (row_shr:4)
+    const int a = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0x5, false);
+    return __builtin_amdgcn_update_dpp(a, v, 0x114, 0xf, 0xa, false);
+  } else if constexpr (O == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);   // row_ror:8
+  else if constexpr (O == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // {odd rows <- even rows of the copy, even rows <- odd rows}
+    return ((threadIdx.x & 16) != 0) ? (int)r[0] : (int)r[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return ((threadIdx.x & 32) != 0) ? (int)r[0] : (int)r[1];
+  }
+}
+template <int O>
+__device__ __forceinline__ double wave_xor(double v) {
+  return __hiloint2double(wave_xor<O>(__double2hiint(v)), wave_xor<O>(__double2loint(v)));
+}
+__device__ __forceinline__ double wave_sum(double v) {   // same pairing and order as the xor butterfly 32, 16, ..., 1
+  v += wave_xor<32>(v); v += wave_xor<16>(v); v += wave_xor<8>(v); v += wave_xor<4>(v); v += wave_xor<2>(v); v += wave_xor<1>(v);
   return v;
 }
 // NB independent sums over the 64 lanes at once: each halving step keeps one half of the values and hands the
@@ -66,11 +89,11 @@ __device__ __forceinline__ void wave_sum_bins_step(T (&v)[NB], int lane) {
     for (int j = 0; j < h; ++j) {
       const T send = upper ? v[j] : v[j + h];
       const T keep = upper ? v[j + h] : v[j];
-      v[j] = keep + __shfl_xor(send, O, 64);
+      v[j] = keep + wave_xor<O>(send);
     }
     wave_sum_bins_step<h, O / 2, NB, T>(v, lane);
   } else if constexpr (O > 0) {
-    v[0] += __shfl_xor(v[0], O, 64);
+    v[0] += wave_xor<O>(v[0]);
     wave_sum_bins_step<1, O / 2, NB, T>(v, lane);
   }
 }
@@ -83,13 +106,11 @@ __device__ __forceinline__ int wave_bin_of_lane(int lane) {
   return q == 0 ? 0 : (lane >> (6 - q)) & (NB - 1);
 }
 __device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  v = fmin(v, wave_xor<32>(v)); v = fmin(v, wave_xor<16>(v)); v = fmin(v, wave_xor<8>(v)); v = fmin(v, wave_xor<4>(v)); v = fmin(v, wave_xor<2>(v)); v = fmin(v, wave_xor<1>(v));
   return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  v = fmax(v, wave_xor<32>(v)); v = fmax(v, wave_xor<16>(v)); v = fmax(v, wave_xor<8>(v)); v = fmax(v, wave_xor<4>(v)); v = fmax(v, wave_xor<2>(v)); v = fmax(v, wave_xor<1>(v));
   return v;
 }
 
