@@ -254,6 +254,12 @@ int S4B_FN(get_trace)(s4b_sampler* s, int64_t cap_records, int32_t* out, int64_t
 /* DFS leaf rank of every training observation in tree t (n int32) */
 int S4B_FN(get_leaf_assignment)(s4b_sampler* s, int32_t tree, int32_t* out);
 /* counters: {log-density gradient evaluations, tree updates, device kernel launches} */
+/* Not a reference routine.  Hint that `chains` samplers share this sampler's device (R/stan4bart_fit.R:515-533 runs the chains of
+ * one fit in parallel workers; here they can be host threads on one GPU).  The default tree update keeps every CU busy with one
+ * register-heavy workgroup, which is fastest for a chain that has the device to itself; with three or more chains per device the
+ * sampler switches to the two-kernel tree update, which leaves room for the other chains' kernels (higher aggregate rate).  Same
+ * draws either way.  May be called at any time between runs. */
+int S4B_FN(set_device_sharing)(s4b_sampler* s, int32_t chains);
 int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
 
 /* NUTS totals over all transitions since creation: {transitions, sum of treedepth__, sum of n_leapfrog__, divergent transitions}

@@ -273,7 +273,7 @@ class Sampler:
             "set_trace": [vp, i32], "get_trace": [vp, i64, ip, C.POINTER(i64)],
             "get_leaf_assignment": [vp, i32, ip], "get_counters": [vp, C.POINTER(i64)], "get_nuts_stats": [vp, dp],
             "profile_sweep": [vp, i32, dp], "profile_leapfrog": [vp, i32, dp],
-            "set_progress": [vp, PROGRESS, vp],
+            "set_progress": [vp, PROGRESS, vp], "set_device_sharing": [vp, i32],
         }
         for name, argtypes in sig.items():
             fn = getattr(self._lib, self._pfx + name, None)
@@ -403,6 +403,12 @@ class Sampler:
         self._progress_py = fn
         self._progress_c = PROGRESS(lambda user, it, n, w: int(bool(fn(it, n, bool(w))))) if fn is not None else PROGRESS()
         self._check(self._f("set_progress")(self._h, self._progress_c, None))
+
+    def set_device_sharing(self, chains: int):
+        """Hint: ``chains`` samplers share this sampler's GPU (three or more: the tree update that leaves room for the others)."""
+        fn = getattr(self._lib, self._pfx + "set_device_sharing", None)
+        if fn is not None:          # (the CPU oracle has no such notion)
+            self._check(fn(self._h, int(chains)))
 
     def set_trace(self, enable: bool):
         self._check(self._f("set_trace")(self._h, int(enable)))

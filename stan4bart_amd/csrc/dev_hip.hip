@@ -1828,6 +1828,7 @@ class DevHip {
       // more waves streaming (4 per SIMD instead of 2)
       useFused_ = perThread <= 8 && ldsStep_ + 24 * 1024 <= 160 * 1024;
       if (const char* f = getenv("S4B_FUSED")) useFused_ = atoi(f) != 0 && perThread <= 255 && ldsStep_ + 24 * 1024 <= 160 * 1024;
+      fusedAuto_ = useFused_;
       a.partF = zalloc<double>((size_t)2 * 3 * a.binCap * a.gridF);
     }
     int32_t* nc = alloc<int32_t>((size_t)P_); upload(nc, d.numCuts, (size_t)P_); a.numCuts = nc;
@@ -2140,6 +2141,16 @@ class DevHip {
     out[6] = ms * 1000.0 / nSweeps;
   }
   bool fused() const { return useFused_; }
+  // Hint: `chains` samplers share this device.  The fused launch keeps every CU busy with one workgroup of 8 register-heavy waves,
+  // which leaves no room for another chain's kernels: with three or more chains per device the two-kernel tree update gives the
+  // higher aggregate rate (measured at n = 1e6: 4 chains 512 vs 425 iterations/s; 2 chains 379 vs 403).  Between sweeps both
+  // paths start from the same state (main tree arrays, generator slot 0), so the switch is safe at any call boundary.
+  void set_device_sharing(int chains) {
+    const bool want = fusedAuto_ && chains < 3;
+    if (want == useFused_) return;
+    useFused_ = want;
+    if (graphExec_) { (void)hipGraphExecDestroy(graphExec_); graphExec_ = nullptr; }
+  }
   void profile_sweep(int nSweeps, int thin, double* out) {
     if (useFused_) { profile_sweep_fused(nSweeps, thin, out); return; }
     const int perSweep = 2 * T_ * thin + thin;
@@ -2355,7 +2366,7 @@ class DevHip {
 
   int device_ = 0; hipStream_t stream_ = nullptr; hipEvent_t evStart_ = nullptr, evStop_ = nullptr;
   int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1; bool binary_ = false;
-  size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0; bool useFused_ = false;
+  size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0; bool useFused_ = false, fusedAuto_ = false;
   double dbgSweepMs_ = 0; int dbgSweeps_ = 0;
   hipGraph_t graph_ = nullptr; hipGraphExec_t graphExec_ = nullptr; int graphTrace_ = -1; bool useGraph_ = true;
   BartArrays a_; StanArrays s_;

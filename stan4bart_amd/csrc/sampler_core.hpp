@@ -576,6 +576,7 @@ class SamplerCore {
   }
 
   void set_trace(bool on) { live(); dev_.set_trace(on); }
+  void set_device_sharing(int chains) { live(); dev_.set_device_sharing(chains); }
   int64_t get_trace(int64_t cap, int32_t* out) { live(); return dev_.get_trace(cap, out); }
   void leaf_assignment(int t, int32_t* out) {
     live();

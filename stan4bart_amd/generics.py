@@ -389,6 +389,8 @@ def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=N
         s = make_sampler(args, chain_rng.state)
         r = {}
         try:
+            if cores > 1 and chains > 1 and hasattr(s, "set_device_sharing"):
+                s.set_device_sharing(min(cores, chains))      # host threads sharing one GPU
             names_box[:] = [s.stan_par_names()]
             if warmup > 0:
                 r["warmup"] = s.run(warmup, True, 0)

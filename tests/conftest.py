@@ -227,8 +227,9 @@ def teacher_forced(oracle_lib, lib, prefix, args, seed=12345, patch=None, compar
     return np.array(rows).T, window_ends
 
 
-def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True):
-    """stan4bart_fit_worker (reference R/stan4bart_fit.R:33-60) with the diagnostics the parity tests compare."""
+def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True, sharing=None):
+    """stan4bart_fit_worker (reference R/stan4bart_fit.R:33-60) with the diagnostics the parity tests compare.
+    ``sharing = (before_warmup, before_sampling)``: device-sharing hints given at those two points (None: not given)."""
     import copy
     from stan4bart_amd import RRng
     from stan4bart_amd.abi import Sampler
@@ -240,12 +241,16 @@ def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True):
     try:
         if trace:
             s.set_trace(True)
+        if sharing is not None and sharing[0] is not None:
+            s.set_device_sharing(sharing[0])
         traces = []
         if args.warmup > 0:
             out["warmup"] = s.run(args.warmup, True, results_type)
             if trace:
                 traces.append(s.get_trace())
         s.disengage_adaptation()
+        if sharing is not None and sharing[1] is not None:
+            s.set_device_sharing(sharing[1])
         out["sample"] = s.run(args.iter - args.warmup, False, results_type)
         if trace:
             traces.append(s.get_trace())

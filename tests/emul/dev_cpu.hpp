@@ -239,6 +239,7 @@ class DevCpu {
     }
   }
   void profile_leapfrog(int, const double*, const double*, double* out) { out[0] = out[1] = out[2] = 0.0; }
+  void set_device_sharing(int) {}
   void profile_sweep(int nSweeps, int thin, double* out) { for (int i = 0; i < 8; ++i) out[i] = 0.0; for (int k = 0; k < nSweeps; ++k) sweep(thin); }
   void test_fits(double* out) {
     for (size_t i = 0; i < nTest_; ++i) {

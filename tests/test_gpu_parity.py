@@ -166,6 +166,16 @@ def test_trees_with_more_than_128_node_slots(oracle_lib, hip_lib):
     assert_chain_parity(a, b, stan=False)
 
 
+@pytest.mark.parametrize("sharing", [(4, None), (None, 4), (4, 1)])
+def test_device_sharing_hint_switches_the_tree_update_without_changing_the_draws(oracle_lib, hip_lib, sharing):
+    """s4b_set_device_sharing: three or more chains per GPU -> two-kernel tree update, fewer -> the fused launch; given before the
+    warm-up, between warm-up and sampling, and back again — the chain is the oracle's either way."""
+    args, _ = friedman_case(n=3000, T=12, warmup=8, iter=16, ranef=True)
+    a = run_chain(oracle_lib, "orc_", args)
+    b = run_chain(hip_lib, "s4b_", args, sharing=sharing)
+    assert_chain_parity(a, b)
+
+
 def test_odd_predictors_and_cut_counts(oracle_lib, hip_lib):
     from test_host_logic import _odd_predictors_case
     args = _odd_predictors_case()

@@ -11,13 +11,16 @@ from stan4bart_amd.fit import chain_seeds
 
 lib = load_library()
 n, p, trees, warm, steps = 1_000_000, 50, 200, 5, 20
+design = bench.friedman_design(n, p, 0, 1, lambda: None)
 for C in (1, 2, 3, 4, 6):
     samplers = []
     for c in range(C):
-        args = bench.build_case(n, p, trees, 0, warm, steps)
+        args = bench.case_from_design(design, p, trees, 0, warm + steps, 2 * (warm + steps))
         rng = RRng(int(chain_seeds(20260101, C)[c]))
         args.seed = int(rng.sample_int(2147483647, 1)[0])
         samplers.append(Sampler(lib, "s4b_", args, rng.state))
+        if "--no-hint" not in sys.argv:
+            samplers[-1].set_device_sharing(C)
     def work(s, k):
         s.run(k, True, 0)
     th = [threading.Thread(target=work, args=(s, warm)) for s in samplers]
