@@ -39,10 +39,13 @@ def test_hip_matches_oracle(oracle_lib, hip_lib, kw):
 
 
 @pytest.mark.parametrize("n", [5000, 1003])
-def test_bart_block_long_run(oracle_lib, hip_lib, n):
+@pytest.mark.parametrize("two_kernel", [False, True], ids=["fused", "two-kernel"])
+def test_bart_block_long_run(oracle_lib, hip_lib, n, two_kernel):
+    """2400 tree updates; both tree-update paths of the device layer (small n takes the fused launch by itself; the sharing hint
+    selects the two-kernel path, which large n and several chains per GPU use)."""
     args, _ = friedman_case(n=n, T=40, warmup=30, iter=60)
     a = run_chain(oracle_lib, "orc_", args, results_type=1)
-    b = run_chain(hip_lib, "s4b_", args, results_type=1)
+    b = run_chain(hip_lib, "s4b_", args, results_type=1, sharing=(4, None) if two_kernel else None)
     assert len(a["trace"]) == 40 * 60 and set(np.unique(a["trace"][:, 0])) == {0, 1, 2, 3}
     assert_chain_parity(a, b, stan=False)
 
