@@ -1216,7 +1216,10 @@ __global__ __launch_bounds__(BLOCK) void k_latents(BartArrays a) {
 // ahead, whole Mersenne-Twister blocks at a time, by all waves; a short history of blocks is kept so that the generator state
 // handed back is the one a sequential consumer would leave.
 constexpr int LB2 = 1024;
-constexpr int L_RING = 4096, L_CH = 2048, L_NB = 32, L_BLK = 8, L_EMAX = 20;
+#ifndef S4B_L_NB
+#define S4B_L_NB 32
+#endif
+constexpr int L_RING = 4096, L_CH = 2048, L_NB = S4B_L_NB, L_BLK = 8, L_EMAX = 20;
 struct Lat2Lds {
   uint32_t (*mt)[626]; uint32_t* U; double* Z; double* E; uint8_t* EL; double* lower; double (*X)[64]; uint8_t (*T)[64];
 };
@@ -1361,16 +1364,27 @@ __global__ __launch_bounds__(LB2) void k_latents2(BartArrays a, double* xacc) {
       if (wv == 0) {
         int t[L_NB];
 #pragma unroll
-        for (int i = 0; i < L_NB; ++i) t[i] = i < nbatch ? (int)S.T[i][lane] : 255;
+        for (int i = 0; i < L_NB; ++i) t[i] = (int)S.T[i][lane];      // unconditional: all reads in flight together (a read under a
+#pragma unroll
+        for (int i = 0; i < L_NB; ++i) t[i] = i < nbatch ? t[i] : 255;   // condition is a branch with its own wait)
+#ifdef S4B_CONTROL_TIMING
+        __builtin_amdgcn_s_waitcnt(0); const long long tr1 = wall_clock64();
+#endif
         int o = 0, cnt = 0, alive = 1, mine = 0;
 #pragma unroll
         for (int i = 0; i < L_NB; ++i) {
-          if (alive) {
-            const int nx = __builtin_amdgcn_readlane(t[i], o);
-            if (nx == 255) alive = 0;
-            else { mine = lane == i ? o : mine; ++cnt; o = nx; if (o >= 64) alive = 0; }
-          }
+          // branch-free (selects on wave-uniform values): a branch per step costs more than the step
+          const int nx = __builtin_amdgcn_readlane(t[i], o & 63);
+          const int take = alive & (nx != 255 ? 1 : 0);     // observation i is resolved from slack o
+          mine = (lane == i && take) ? o : mine;
+          cnt += take;
+          o = take ? nx : o;
+          alive = take & (nx < 64 ? 1 : 0);
         }
+#ifdef S4B_CONTROL_TIMING
+        const long long tr2 = wall_clock64();
+        if (lane == 0) { g_dbg[34] += tr1 - tl2; g_dbg[35] += tr2 - tr1; }
+#endif
         if (lane < cnt) xacc[c0 + done + lane] = S.X[lane][mine];
         if (lane == 0) {
           shBase = base + 2 * cnt + o; shCnt = cnt;
@@ -1395,8 +1409,9 @@ __global__ __launch_bounds__(LB2) void k_latents2(BartArrays a, double* xacc) {
     if (tid == 0) { a.rng->mti = idx; a.rng->pad = 0; }
   }
 #ifdef S4B_CONTROL_TIMING
-  if (tid == 0) { printf("DBG k_latents2: %lld batches (%.1f obs each), per batch us: refill %.2f build %.2f resolve+sync %.2f\n", g_dbg[39], (double)a.n / (double)g_dbg[39],
-                         g_dbg[36] / 100.0 / g_dbg[39], g_dbg[37] / 100.0 / g_dbg[39], g_dbg[38] / 100.0 / g_dbg[39]); g_dbg[36] = g_dbg[37] = g_dbg[38] = g_dbg[39] = 0; }
+  if (tid == 0) { printf("DBG k_latents2: %lld batches (%.1f obs each), per batch us: refill %.2f build %.2f resolve+sync %.2f (table read %.2f, chain %.2f)\n", g_dbg[39], (double)a.n / (double)g_dbg[39],
+                         g_dbg[36] / 100.0 / g_dbg[39], g_dbg[37] / 100.0 / g_dbg[39], g_dbg[38] / 100.0 / g_dbg[39], g_dbg[34] / 100.0 / g_dbg[39], g_dbg[35] / 100.0 / g_dbg[39]);
+                         g_dbg[34] = g_dbg[35] = g_dbg[36] = g_dbg[37] = g_dbg[38] = g_dbg[39] = 0; }
 #endif
 }
 __global__ __launch_bounds__(BLOCK) void k_latents_finish(BartArrays a, const double* xacc) {
