@@ -257,8 +257,9 @@ int S4B_FN(get_leaf_assignment)(s4b_sampler* s, int32_t tree, int32_t* out);
 /* Not a reference routine.  Hint that `chains` samplers share this sampler's device (R/stan4bart_fit.R:515-533 runs the chains of
  * one fit in parallel workers; here they can be host threads on one GPU).  The default tree update keeps every CU busy with one
  * register-heavy workgroup, which is fastest for a chain that has the device to itself; with three or more chains per device the
- * sampler switches to the two-kernel tree update, which leaves room for the other chains' kernels (higher aggregate rate).  Same
- * draws either way.  May be called at any time between runs. */
+ * sampler switches to the two-kernel tree update, which leaves room for the other chains' kernels (higher aggregate rate).  The
+ * same chain either way: identical tree moves and generator stream, floating-point values equal up to the summation order of the
+ * per-bin sums (1e-15 relative).  May be called at any time between runs. */
 int S4B_FN(set_device_sharing)(s4b_sampler* s, int32_t chains);
 int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
 

@@ -293,11 +293,20 @@ def test_concurrent_chains_on_hip(hip_lib):
     mk = lambda a, st: Sampler(hip_lib, "s4b_", a, st)
     fit = stan4bart(d["y"], xb, X=X, groups=groups, chains=3, cores=3, seed=42, iter=12, warmup=6,
                     bart_args={"n.trees": 25, "keepTrees": True}, make_sampler=mk)
+    def mk_shared(a, st):   # what stan4bart(cores = 3) tells every sampler: three chains share the device
+        s = Sampler(hip_lib, "s4b_", a, st)
+        s.set_device_sharing(3)
+        return s
     for c in range(3):
         args = make_sampler_args(d["y"], xb, X=X, groups=groups, iter=12, warmup=6, bart_args={"n.trees": 25, "keepTrees": True})
-        alone = fit_worker(mk, args, RRng(int(chain_seeds(42, 3)[c])))
+        alone = fit_worker(mk_shared, args, RRng(int(chain_seeds(42, 3)[c])))
         np.testing.assert_array_equal(alone["sample"]["stan"], fit.stan[:, :, c])
         np.testing.assert_array_equal(alone["sample"]["bart"]["train"], fit.bart_train[:, :, c])
+        if c == 0:   # the same chain with the device to itself (fused tree update): another summation order, the same chain
+            solo = fit_worker(mk, args, RRng(int(chain_seeds(42, 3)[c])))
+            np.testing.assert_allclose(solo["sample"]["stan"], fit.stan[:, :, c], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(solo["sample"]["bart"]["train"], fit.bart_train[:, :, c], rtol=1e-9, atol=1e-12)
+            np.testing.assert_array_equal(solo["sample"]["bart"]["varcount"], fit.bart_varcount[:, :, c])
     p = fit.predict(x_bart=xb[:9], X=X[:9], groups=[type(g)(np.asarray(g.levels)[:9], None if g.slopes is None else np.asarray(g.slopes)[:9], g.name)
                                                     for g in groups], type="ev", combine_chains=False)
     np.testing.assert_allclose(p, fit.extract("ev", combine_chains=False)[:9], rtol=1e-9, atol=1e-9)
