@@ -261,6 +261,17 @@ int S4B_FN(get_leaf_assignment)(s4b_sampler* s, int32_t tree, int32_t* out);
  * same chain either way: identical tree moves and generator stream, floating-point values equal up to the summation order of the
  * per-bin sums (1e-15 relative).  May be called at any time between runs. */
 int S4B_FN(set_device_sharing)(s4b_sampler* s, int32_t chains);
+/* Not a reference routine.  Which device code runs a tree update: 0 automatic (default), 1 two kernels per tree (k_tree + k_control),
+ * 2 one fused launch per tree (k_step), 3 lagged (k_lag: the O(N) pass of a launch never waits for a decision; the decision of the
+ * tree before runs beside it and corrects its statistics through an integer contingency table).  A request the sampler cannot
+ * honour (weights or a node capacity beyond the LDS budget for 3, more than 255 quads per thread for 2) falls back to the next
+ * path down.  The same chain on every path (see set_device_sharing).  May be called at any time between runs.
+ * get_tree_path: out[0] = the request, out[1] = the path in effect (1..3). */
+int S4B_FN(set_tree_path)(s4b_sampler* s, int32_t path);
+int S4B_FN(get_tree_path)(s4b_sampler* s, int32_t out[2]);
+/* lagged path only (zeros otherwise): out = {sweeps, launches used per sweep, repair launches per sweep (a speculated proposal image
+ * did not hold), slow (one step at a time) passes, decisions without a statistics pass beside them, host top-ups} since creation */
+int S4B_FN(get_lag_stats)(s4b_sampler* s, double out[6]);
 int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
 
 /* NUTS totals over all transitions since creation: {transitions, sum of treedepth__, sum of n_leapfrog__, divergent transitions}

@@ -274,6 +274,7 @@ class Sampler:
             "get_leaf_assignment": [vp, i32, ip], "get_counters": [vp, C.POINTER(i64)], "get_nuts_stats": [vp, dp],
             "profile_sweep": [vp, i32, dp], "profile_leapfrog": [vp, i32, dp],
             "set_progress": [vp, PROGRESS, vp], "set_device_sharing": [vp, i32],
+            "set_tree_path": [vp, i32], "get_tree_path": [vp, ip], "get_lag_stats": [vp, dp],
         }
         for name, argtypes in sig.items():
             fn = getattr(self._lib, self._pfx + name, None)
@@ -409,6 +410,32 @@ class Sampler:
         fn = getattr(self._lib, self._pfx + "set_device_sharing", None)
         if fn is not None:          # (the CPU oracle has no such notion)
             self._check(fn(self._h, int(chains)))
+
+    TREE_PATHS = {"auto": 0, "two-kernel": 1, "fused": 2, "lagged": 3}
+
+    def set_tree_path(self, path):
+        """Device code of a tree update: "auto", "two-kernel" (k_tree + k_control), "fused" (k_step) or "lagged" (k_lag)."""
+        fn = getattr(self._lib, self._pfx + "set_tree_path", None)
+        if fn is not None:          # (the CPU oracle has one path)
+            self._check(fn(self._h, int(self.TREE_PATHS.get(path, path))))
+
+    def get_tree_path(self):
+        """(requested, in effect) as names."""
+        fn = getattr(self._lib, self._pfx + "get_tree_path", None)
+        if fn is None:
+            return ("auto", "oracle")
+        out = np.zeros(2, dtype=np.int32)
+        self._check(fn(self._h, _ip(out)))
+        names = {v: k for k, v in self.TREE_PATHS.items()}
+        return (names[int(out[0])], names[int(out[1])])
+
+    def get_lag_stats(self) -> dict:
+        out = np.zeros(6, dtype=np.float64)
+        fn = getattr(self._lib, self._pfx + "get_lag_stats", None)
+        if fn is not None:
+            self._check(fn(self._h, _dp(out)))
+        return {"sweeps": out[0], "launches_per_sweep": out[1], "repairs_per_sweep": out[2], "slow_passes": out[3],
+                "decisions_alone": out[4], "host_top_ups": out[5]}
 
     def set_trace(self, enable: bool):
         self._check(self._f("set_trace")(self._h, int(enable)))

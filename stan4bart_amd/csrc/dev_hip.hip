@@ -539,7 +539,7 @@ struct StepScalars {
   __device__ __forceinline__ double f64(int l) const { return __hiloint2double(__builtin_amdgcn_readlane(dhi, l), __builtin_amdgcn_readlane(dlo, l)); }
   __device__ __forceinline__ void proposal(Proposal& p) const {
     p.type = i32(0); p.status = i32(1); p.node = i32(2); p.var = i32(3); p.split = i32(4); p.nbA = i32(5); p.nbB = i32(6); p.hwm = i32(7);
-    p.newLeft = i32(8); p.newRight = i32(9); p.pad0 = 0; p.pad1 = 0;
+    p.newLeft = i32(8); p.newRight = i32(9); p.pad0 = i32(10); p.pad1 = i32(11);
     p.priorRatio = f64w(12); p.transRatio = f64w(14); p.XLogPi = f64w(16); p.YLogPi = f64w(18);
   }
 };
@@ -559,7 +559,7 @@ __device__ __forceinline__ void step_scalars_load(StepScalars& g, const BartArra
 // proposal record -> global, one dword per lane
 __device__ __forceinline__ void proposal_store(const Proposal& p, Proposal* dst, int lane) {
   int w = 0;
-  const int v[20] = {p.type, p.status, p.node, p.var, p.split, p.nbA, p.nbB, p.hwm, p.newLeft, p.newRight, 0, 0,
+  const int v[20] = {p.type, p.status, p.node, p.var, p.split, p.nbA, p.nbB, p.hwm, p.newLeft, p.newRight, p.pad0, p.pad1,
                      __double2loint(p.priorRatio), __double2hiint(p.priorRatio), __double2loint(p.transRatio), __double2hiint(p.transRatio),
                      __double2loint(p.XLogPi), __double2hiint(p.XLogPi), __double2loint(p.YLogPi), __double2hiint(p.YLogPi)};
 #pragma unroll
@@ -870,6 +870,7 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
 }
 
 #include "dev_step.inc"
+#include "dev_lag.inc"
 
 // ------------------------------------------------------------------------------------------------
 // k_apply: R_i += mu_old[leaf] - mu_new[leaf'], relabel observations under the accepted move's root
@@ -1726,6 +1727,9 @@ class DevHip {
   ~DevHip() {
     if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
     if (graph_) (void)hipGraphDestroy(graph_);
+    if (lagExec_) (void)hipGraphExecDestroy(lagExec_);
+    if (lagGraph_) (void)hipGraphDestroy(lagGraph_);
+    if (pinnedLag_) (void)hipHostFree(pinnedLag_);
     for (void* p : allocs_) (void)hipFree(p);
     if (pinned_) (void)hipHostFree(pinned_);
     if (pinnedAcc_) (void)hipHostFree(pinnedAcc_);
@@ -1841,10 +1845,19 @@ class DevHip {
       ldsStep_ = step_lds_bytes(nc_, d.weights != nullptr);
       // automatic choice: the fused launch wins while a tree update is latency-bound; at large n the two-kernel path keeps
       // more waves streaming (4 per SIMD instead of 2)
-      useFused_ = perThread <= 8 && ldsStep_ + 24 * 1024 <= 160 * 1024;
-      if (const char* f = getenv("S4B_FUSED")) useFused_ = atoi(f) != 0 && perThread <= 255 && ldsStep_ + 24 * 1024 <= 160 * 1024;
-      fusedAuto_ = useFused_;
+      fusedOk_ = perThread <= 255 && ldsStep_ + 24 * 1024 <= 160 * 1024;
+      fusedAuto_ = perThread <= 8 && fusedOk_;
       a.partF = zalloc<double>((size_t)2 * 3 * a.binCap * a.gridF);
+      // lagged path (dev_lag.inc): the same grid; one control workgroup + pass workgroups that never wait for a decision
+      ldsLag_ = lag_lds_bytes(nc_);
+      lagOk_ = d.weights == nullptr && ldsLag_ + 40 * 1024 <= 160 * 1024 && a.gridF <= 256;
+      if (lagOk_) {
+        lag_.desc = zalloc<int32_t>((size_t)2 * LD_WORDS); lag_.apply = zalloc<LagApply>(2); lag_.gtab = zalloc<uint32_t>((size_t)2 * LAG_XCD * LAG_TAB);
+        lag_.cells = zalloc<uint8_t>((size_t)3 * a.npad); lag_.stat = zalloc<int32_t>(LS_WORDS);
+        HIP_OK(hipHostMalloc(&pinnedLag_, sizeof(int32_t) * 16, hipHostMallocDefault));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLag_));
+      }
+      choose_path();
     }
     int32_t* nc = alloc<int32_t>((size_t)P_); upload(nc, d.numCuts, (size_t)P_); a.numCuts = nc;
     a.trace = zalloc<StepRecord>((size_t)std::max(1, d.traceCap)); a.traceCount = zalloc<int32_t>(1); a.errFlag = zalloc<int32_t>(1);
@@ -1907,7 +1920,7 @@ class DevHip {
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
     }
     if (ldsApply_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsApply_));
-    if (useFused_ && ldsStep_ > 32 * 1024) {
+    if (fusedOk_ && ldsStep_ > 32 * 1024) {
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsStep_));
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsStep_));
     }
@@ -2015,6 +2028,10 @@ class DevHip {
     }
   }
   void sweep_impl(int thin) {
+    if (path_ == PATH_LAG) {
+      for (int k = 0; k < thin; ++k) { sweep_lag_one(); if (binary_) launch_latents(); }
+      return;
+    }
     if (useGraph_) {
       if (!graphExec_ || graphTrace_ != a_.traceOn) capture_sweep();
       for (int k = 0; k < thin; ++k) {
@@ -2156,17 +2173,120 @@ class DevHip {
     out[6] = ms * 1000.0 / nSweeps;
   }
   bool fused() const { return useFused_; }
+  // ---- lagged path (dev_lag.inc): k_lag_pre + T + 2 launches when every speculated proposal image holds, one more per repair.  The
+  // sweep is replayed from a hipGraph with `lagPlanned_` launches (the trailing ones exit at once); the control workgroup raises
+  // stat[LS_DONE] when the last tree has been folded in, the host tops the sweep up in the rare case the slack was not enough.
+  void launch_lag(int j) { hipLaunchKernelGGL(k_lag, dim3(a_.gridF), dim3(LBLOCK), ldsLag_, stream_, a_, lag_, j); }
+  void capture_lag(int launches) {
+    if (lagExec_) { (void)hipGraphExecDestroy(lagExec_); lagExec_ = nullptr; }
+    if (lagGraph_) { (void)hipGraphDestroy(lagGraph_); lagGraph_ = nullptr; }
+    HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+    hipLaunchKernelGGL(k_lag_pre, dim3(1), dim3(LBLOCK), 0, stream_, a_, lag_);
+    for (int j = 0; j < launches; ++j) launch_lag(j);
+    HIP_OK(hipMemcpyAsync(pinnedLag_, lag_.stat, sizeof(int32_t) * LS_WORDS, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipStreamEndCapture(stream_, &lagGraph_));
+    HIP_OK(hipGraphInstantiate(&lagExec_, lagGraph_, nullptr, nullptr, 0));
+    lagCaptured_ = launches; graphTrace_ = a_.traceOn;
+  }
+  void sweep_lag_one() {
+    const int minLaunches = T_ + 2;
+    // slack: a running estimate of the repairs per sweep plus a margin, in steps of 8 launches (a re-capture costs a millisecond)
+    int want = minLaunches + (int)(lagRepairs_ + 3.0 * std::sqrt(lagRepairs_ + 1.0)) + 2;
+    want = (want + 7) / 8 * 8;
+    int launched;
+    if (useGraph_) {
+      if (!lagExec_ || graphTrace_ != a_.traceOn || want > lagCaptured_ || want + 16 < lagCaptured_) capture_lag(want);
+      HIP_OK(hipGraphLaunch(lagExec_, stream_));
+      launched = lagCaptured_;
+    } else {
+      hipLaunchKernelGGL(k_lag_pre, dim3(1), dim3(LBLOCK), 0, stream_, a_, lag_);
+      for (int j = 0; j < want; ++j) launch_lag(j);
+      HIP_OK(hipMemcpyAsync(pinnedLag_, lag_.stat, sizeof(int32_t) * LS_WORDS, hipMemcpyDeviceToHost, stream_));
+      launched = want;
+    }
+    launches_ += launched + 1;
+    sync();
+    int guard = 0;
+    while (!pinnedLag_[LS_DONE]) {
+      for (int k = 0; k < 8; ++k) launch_lag(launched++);
+      launches_ += 8; ++lagTopUps_;
+      HIP_OK(hipMemcpyAsync(pinnedLag_, lag_.stat, sizeof(int32_t) * LS_WORDS, hipMemcpyDeviceToHost, stream_));
+      sync();
+      if (++guard > 4 * T_ + 64) throw std::runtime_error("lagged tree update: the sweep does not terminate");
+    }
+    const int used = pinnedLag_[LS_LAUNCHES];
+    lagRepairs_ += 0.1 * ((double)(used - minLaunches) - lagRepairs_);
+    lagLaunchesUsed_ += used; lagBubbles_ += pinnedLag_[LS_BUBBLES]; lagSlow_ += pinnedLag_[LS_SLOW]; lagSeq_ += pinnedLag_[LS_SEQ]; ++lagSweeps_;
+  }
+  // tree-update path: 0 automatic, 1 two kernels per tree (k_tree + k_control), 2 fused (k_step), 3 lagged (k_lag)
+  void set_tree_path(int path) {
+    if (path < 0 || path > 3) throw std::invalid_argument("tree path must be 0 (automatic), 1 (two-kernel), 2 (fused) or 3 (lagged)");
+    pathReq_ = path; choose_path();
+  }
+  void get_tree_path(int32_t out[2]) const { out[0] = pathReq_; out[1] = path_; }
+  void lag_stats(double out[6]) const {
+    out[0] = (double)lagSweeps_; out[1] = lagSweeps_ ? (double)lagLaunchesUsed_ / lagSweeps_ : 0.0; out[2] = lagSweeps_ ? (double)lagBubbles_ / lagSweeps_ : 0.0;
+    out[3] = (double)lagSlow_; out[4] = (double)lagSeq_; out[5] = (double)lagTopUps_;
+  }
+  void choose_path() {
+    int want = pathReq_;
+    if (want == 0) want = sharing_ >= 3 ? PATH_TWO : (lagOk_ ? PATH_LAG : (fusedAuto_ ? PATH_FUSED : PATH_TWO));
+    if (want == PATH_LAG && !lagOk_) want = fusedOk_ ? PATH_FUSED : PATH_TWO;
+    if (want == PATH_FUSED && !fusedOk_) want = PATH_TWO;
+    if (want == path_) return;
+    path_ = want; useFused_ = path_ == PATH_FUSED;
+    if (graphExec_) { (void)hipGraphExecDestroy(graphExec_); graphExec_ = nullptr; }
+  }
   // Hint: `chains` samplers share this device.  The fused launch keeps every CU busy with one workgroup of 8 register-heavy waves,
   // which leaves no room for another chain's kernels: with three or more chains per device the two-kernel tree update gives the
   // higher aggregate rate (measured at n = 1e6: 4 chains 512 vs 425 iterations/s; 2 chains 379 vs 403).  Between sweeps both
   // paths start from the same state (main tree arrays, generator slot 0), so the switch is safe at any call boundary.
-  void set_device_sharing(int chains) {
-    const bool want = fusedAuto_ && chains < 3;
-    if (want == useFused_) return;
-    useFused_ = want;
-    if (graphExec_) { (void)hipGraphExecDestroy(graphExec_); graphExec_ = nullptr; }
+  void set_device_sharing(int chains) { sharing_ = chains; choose_path(); }
+  // lagged path: HIP events around every launch of extra sweeps; the average is over launches that did all three things (fold a
+  // tree in, gather statistics, decide beside them), out[3] counts them; out[1] = launches used per sweep, out[2] = repairs per sweep
+  void profile_sweep_lag(int nSweeps, int thin, double* out) {
+    const int cap = 2 * T_ + 64;
+    std::vector<hipEvent_t> ev((size_t)cap + 1);
+    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+    double sum = 0, cnt = 0, used = 0, bub = 0;
+    for (int sIdx = 0; sIdx < nSweeps * thin; ++sIdx) {
+      hipLaunchKernelGGL(k_lag_pre, dim3(1), dim3(LBLOCK), 0, stream_, a_, lag_); ++launches_;
+      int launched = 0;
+      for (;;) {
+        const int from = launched;
+        HIP_OK(hipEventRecord(ev[0], stream_));
+        for (int k = 0; k < cap && (launched < T_ + 2 || k < 8); ++k) { launch_lag(launched++); ++launches_; HIP_OK(hipEventRecord(ev[(size_t)k + 1], stream_)); }
+        HIP_OK(hipMemcpyAsync(pinnedLag_, lag_.stat, sizeof(int32_t) * LS_WORDS, hipMemcpyDeviceToHost, stream_));
+        sync();
+        const int nUsed = pinnedLag_[LS_LAUNCHES];
+        // launches 2 .. used - 3 of an undisturbed sweep are steady; with repairs in between the average includes them (they are
+        // part of what a tree update costs)
+        for (int k = from; k < launched && k < nUsed; ++k) {
+          if (k < 2 || k >= nUsed - 2) continue;
+          float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[(size_t)(k - from)], ev[(size_t)(k - from) + 1]));
+          sum += ms * 1000.0; cnt += 1;
+        }
+        if (pinnedLag_[LS_DONE]) break;
+        if (launched > 8 * T_ + 64) throw std::runtime_error("lagged tree update: the sweep does not terminate");
+      }
+      used += pinnedLag_[LS_LAUNCHES]; bub += pinnedLag_[LS_BUBBLES];
+      if (binary_) launch_latents();
+    }
+    sync();
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    const double ns = (double)nSweeps * thin;
+    out[0] = cnt ? sum / cnt : 0.0; out[3] = cnt;
+    out[1] = used / ns; out[4] = 0.0;
+    out[2] = bub / ns; out[5] = 0.0;
+    HIP_OK(hipEventRecord(evStart_, stream_));
+    for (int sIdx = 0; sIdx < nSweeps; ++sIdx) sweep(thin);
+    HIP_OK(hipEventRecord(evStop_, stream_));
+    sync();
+    float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_));
+    out[6] = ms * 1000.0 / nSweeps;
   }
   void profile_sweep(int nSweeps, int thin, double* out) {
+    if (path_ == PATH_LAG) { profile_sweep_lag(nSweeps, thin, out); return; }
     if (useFused_) { profile_sweep_fused(nSweeps, thin, out); return; }
     const int perSweep = 2 * T_ * thin + thin;
     std::vector<hipEvent_t> ev((size_t)perSweep * 2 + 4);
@@ -2381,7 +2501,11 @@ class DevHip {
 
   int device_ = 0; hipStream_t stream_ = nullptr; hipEvent_t evStart_ = nullptr, evStop_ = nullptr;
   int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1; bool binary_ = false;
-  size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0; bool useFused_ = false, fusedAuto_ = false;
+  size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0, ldsLag_ = 0; bool useFused_ = false, fusedAuto_ = false, fusedOk_ = false, lagOk_ = false;
+  enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_LAG = 3 };
+  int pathReq_ = 0, path_ = 0, sharing_ = 1;
+  LagArrays lag_{}; int32_t* pinnedLag_ = nullptr; hipGraph_t lagGraph_ = nullptr; hipGraphExec_t lagExec_ = nullptr; int lagCaptured_ = 0;
+  double lagRepairs_ = 4.0; int64_t lagLaunchesUsed_ = 0, lagBubbles_ = 0, lagSlow_ = 0, lagSeq_ = 0, lagSweeps_ = 0, lagTopUps_ = 0;
   double dbgSweepMs_ = 0; int dbgSweeps_ = 0;
   hipGraph_t graph_ = nullptr; hipGraphExec_t graphExec_ = nullptr; int graphTrace_ = -1; bool useGraph_ = true;
   BartArrays a_; StanArrays s_;

@@ -94,7 +94,7 @@ struct Proposal {
   int32_t nbA, nbB;          // A bins = current leaves (DFS), B bins = proposed leaves under `node`
   int32_t hwm;               // slots in use: tables are valid for node ids < hwm
   int32_t newLeft, newRight; // birth: slots of the new children
-  int32_t pad0, pad1;
+  int32_t pad0, pad1;        // rule of `node` in the proposed tree: var | cut << 16, left | right << 16 (the O(N) pass starts routing there)
   double priorRatio, transRatio;   // birth/death
   double XLogPi, YLogPi;           // change/swap
 };
@@ -464,7 +464,7 @@ S4B_HD inline bool tv_subtree_pass(const TR& cur, TR& pt, const MV& m, int nd, b
 // included) for node ids < hwm, and binA/binB = -1, insub = 0 there.
 // Returns 0, or -1 when the node capacity is exhausted (the caller raises an error).
 template <class TR, class TBL, class CA, class MV, class RNG>
-S4B_HD inline int propose(const TR& cur, int hwm, const MV& m, RNG* rng, Proposal* pr, TBL& tb, const CA& ca) {
+S4B_HD inline int propose_core(const TR& cur, int hwm, const MV& m, RNG* rng, Proposal* pr, TBL& tb, const CA& ca) {
   TR& pt = tb.prop;
   const int nl = ca.nl, ni = ca.ni;
   for (int i = 0; i < nl; ++i) tb.binA.set(ca.leaf.get(i), (int16_t)i);
@@ -605,6 +605,18 @@ S4B_HD inline int propose(const TR& cur, int hwm, const MV& m, RNG* rng, Proposa
   pr->YLogPi = (ca.logPi - subCur) + subPt;
   for (int i = 0; i < nb; ++i) { int lf = tb.list.get(i); tb.binB.set(lf, (int16_t)(nl + i)); tb.insub.set(lf, 1); }
   pr->nbB = nb; pr->status = 1;
+  return 0;
+}
+
+template <class TR, class TBL, class CA, class MV, class RNG>
+S4B_HD inline int propose(const TR& cur, int hwm, const MV& m, RNG* rng, Proposal* pr, TBL& tb, const CA& ca) {
+  pr->pad0 = 0; pr->pad1 = 0;
+  const int r = propose_core(cur, hwm, m, rng, pr, tb, ca);
+  if (r != 0) return r;
+  // the rule the proposed tree holds at the root of the affected subtree travels with the proposal record
+  const int nd = pr->node;
+  pr->pad0 = (int32_t)(((uint32_t)(int)tb.prop.var.get(nd) & 0xffffu) | ((uint32_t)tb.prop.cut.get(nd) << 16));
+  pr->pad1 = (int32_t)(((uint32_t)(int)tb.prop.left.get(nd) & 0xffffu) | ((uint32_t)(int)tb.prop.right.get(nd) << 16));
   return 0;
 }
 

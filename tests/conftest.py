@@ -227,7 +227,7 @@ def teacher_forced(oracle_lib, lib, prefix, args, seed=12345, patch=None, compar
     return np.array(rows).T, window_ends
 
 
-def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True, sharing=None):
+def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True, sharing=None, tree_path=None):
     """stan4bart_fit_worker (reference R/stan4bart_fit.R:33-60) with the diagnostics the parity tests compare.
     ``sharing = (before_warmup, before_sampling)``: device-sharing hints given at those two points (None: not given)."""
     import copy
@@ -243,6 +243,8 @@ def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True, sharing
             s.set_trace(True)
         if sharing is not None and sharing[0] is not None:
             s.set_device_sharing(sharing[0])
+        if tree_path is not None:
+            s.set_tree_path(tree_path)
         traces = []
         if args.warmup > 0:
             out["warmup"] = s.run(args.warmup, True, results_type)
@@ -262,6 +264,8 @@ def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True, sharing
         out["range"] = s.get_bart_data_range()
         out["pm"] = s.get_parametric_mean()
         out["counters"] = s.get_counters()
+        out["tree_path"] = s.get_tree_path()
+        out["lag_stats"] = s.get_lag_stats()
     finally:
         s.free()
     return out

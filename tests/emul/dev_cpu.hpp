@@ -240,6 +240,9 @@ class DevCpu {
   }
   void profile_leapfrog(int, const double*, const double*, double* out) { out[0] = out[1] = out[2] = 0.0; }
   void set_device_sharing(int) {}
+  void set_tree_path(int path) { if (path < 0 || path > 3) throw std::invalid_argument("tree path must be 0 (automatic), 1 (two-kernel), 2 (fused) or 3 (lagged)"); pathReq_ = path; }
+  void get_tree_path(int32_t out[2]) const { out[0] = pathReq_; out[1] = 1; }
+  void lag_stats(double out[6]) const { for (int i = 0; i < 6; ++i) out[i] = 0.0; }
   void profile_sweep(int nSweeps, int thin, double* out) { for (int i = 0; i < 8; ++i) out[i] = 0.0; for (int k = 0; k < nSweeps; ++k) sweep(thin); }
   void test_fits(double* out) {
     for (size_t i = 0; i < nTest_; ++i) {
@@ -345,7 +348,7 @@ class DevCpu {
   Scratch sc_[2];
   std::vector<StepRecord> trace_;
   MTState rng_; ScaleState scale_; BartArrays a_;
-  int32_t traceCount_ = 0, err_ = 0; int64_t launches_ = 0;
+  int32_t traceCount_ = 0, err_ = 0; int64_t launches_ = 0; int pathReq_ = 0;
 };
 
 }  // namespace s4b
