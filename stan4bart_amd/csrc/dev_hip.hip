@@ -2186,7 +2186,7 @@ class DevHip {
     HIP_OK(hipMemcpyAsync(pinnedLag_, lag_.stat, sizeof(int32_t) * LS_WORDS, hipMemcpyDeviceToHost, stream_));
     HIP_OK(hipStreamEndCapture(stream_, &lagGraph_));
     HIP_OK(hipGraphInstantiate(&lagExec_, lagGraph_, nullptr, nullptr, 0));
-    lagCaptured_ = launches; graphTrace_ = a_.traceOn;
+    lagCaptured_ = launches; lagTrace_ = a_.traceOn;
   }
   void sweep_lag_one() {
     const int minLaunches = T_ + 2;
@@ -2195,7 +2195,7 @@ class DevHip {
     want = (want + 7) / 8 * 8;
     int launched;
     if (useGraph_) {
-      if (!lagExec_ || graphTrace_ != a_.traceOn || want > lagCaptured_ || want + 16 < lagCaptured_) capture_lag(want);
+      if (!lagExec_ || lagTrace_ != a_.traceOn || want > lagCaptured_ || want + 16 < lagCaptured_) capture_lag(want);
       HIP_OK(hipGraphLaunch(lagExec_, stream_));
       launched = lagCaptured_;
     } else {
@@ -2274,6 +2274,25 @@ class DevHip {
     }
     sync();
     for (auto& e : ev) (void)hipEventDestroy(e);
+#ifdef S4B_LAG_TIMING
+    { unsigned long long h[32]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lag), sizeof(h)));
+      const double kp = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0, kc = h[8] ? 1.0 / (100.0 * (double)h[8]) : 0.0;
+      fprintf(stderr, "LAGT pass workgroup 100, us from its start (avg over %llu launches): descriptor %.2f, tables staged %.2f, quads done %.2f, sums reduced %.2f, end %.2f\n",
+              h[0], h[1] * kp, h[2] * kp, (double)(h[3] - h[6]) * kp, (double)(h[4] - h[6]) * kp, (double)(h[5] - h[6]) * kp);
+      fprintf(stderr, "LAGT control workgroup, us from its start (avg over %llu launches): reducers done %.2f, wave 0 has the totals %.2f, decided %.2f, wave 0 at the barrier %.2f, images drawn %.2f, barrier passed %.2f, end %.2f\n",
+              h[8], h[9] * kc, h[10] * kc, h[11] * kc, h[12] * kc, h[13] * kc, h[14] * kc, h[15] * kc);
+      { static unsigned long long ws[256], we[256];
+        HIP_OK(hipMemcpyFromSymbol(ws, HIP_SYMBOL(g_lagS), sizeof(ws))); HIP_OK(hipMemcpyFromSymbol(we, HIP_SYMBOL(g_lagE), sizeof(we)));
+        const int G = a_.gridF; unsigned long long s0 = ~0ull; for (int b = 0; b < G; ++b) if (ws[b] && ws[b] < s0) s0 = ws[b];
+        const double k = h[8] ? 1.0 / (100.0 * (double)h[8]) : 0.0;
+        double lastStart = 0, lastEnd = 0, firstEnd = 1e30; int bS = 0, bE = 0;
+        for (int b = 0; b < G; ++b) { const double st = (double)(ws[b] - s0) * k, en = (double)(we[b] - s0) * k; if (st > lastStart) { lastStart = st; bS = b; } if (en > lastEnd) { lastEnd = en; bE = b; } if (en < firstEnd) firstEnd = en; }
+        fprintf(stderr, "LAGT workgroups (avg us after the earliest start): last start %.2f (block %d), first end %.2f, last end %.2f (block %d); control workgroup start %.2f end %.2f; blocks 0, 100, 200 start %.2f %.2f %.2f end %.2f %.2f %.2f\n",
+                lastStart, bS, firstEnd, lastEnd, bE, (double)(ws[G - 1] - s0) * k, (double)(we[G - 1] - s0) * k,
+                (double)(ws[0] - s0) * k, (double)(ws[100] - s0) * k, (double)(ws[200] - s0) * k, (double)(we[0] - s0) * k, (double)(we[100] - s0) * k, (double)(we[200] - s0) * k);
+        memset(ws, 0, sizeof(ws)); HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_lagS), ws, sizeof(ws))); HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_lagE), ws, sizeof(ws))); }
+      unsigned long long z[32] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_lag), z, sizeof(z))); }
+#endif
     const double ns = (double)nSweeps * thin;
     out[0] = cnt ? sum / cnt : 0.0; out[3] = cnt;
     out[1] = used / ns; out[4] = 0.0;
@@ -2504,7 +2523,7 @@ class DevHip {
   size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0, ldsLag_ = 0; bool useFused_ = false, fusedAuto_ = false, fusedOk_ = false, lagOk_ = false;
   enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_LAG = 3 };
   int pathReq_ = 0, path_ = 0, sharing_ = 1;
-  LagArrays lag_{}; int32_t* pinnedLag_ = nullptr; hipGraph_t lagGraph_ = nullptr; hipGraphExec_t lagExec_ = nullptr; int lagCaptured_ = 0;
+  LagArrays lag_{}; int32_t* pinnedLag_ = nullptr; hipGraph_t lagGraph_ = nullptr; hipGraphExec_t lagExec_ = nullptr; int lagCaptured_ = 0, lagTrace_ = -1;
   double lagRepairs_ = 4.0; int64_t lagLaunchesUsed_ = 0, lagBubbles_ = 0, lagSlow_ = 0, lagSeq_ = 0, lagSweeps_ = 0, lagTopUps_ = 0;
   double dbgSweepMs_ = 0; int dbgSweeps_ = 0;
   hipGraph_t graph_ = nullptr; hipGraphExec_t graphExec_ = nullptr; int graphTrace_ = -1; bool useGraph_ = true;
