@@ -1841,7 +1841,7 @@ class DevHip {
       if (const char* g = getenv("S4B_GRIDF")) { int v = atoi(g); if (v >= 2 && v <= F_GRID_MAX) a.gridF = v; }
       const int64_t passThreads = (int64_t)(a.gridF - 1) * F_PT;
       const int64_t perThread = (nQuads + passThreads - 1) / passThreads;
-      a.candStride = (int64_t)cand_bytes(nc_); a.candBase = zalloc<unsigned char>((size_t)4 * cand_bytes(nc_));
+      a.candStride = (int64_t)cand_bytes(nc_); a.candBase = zalloc<unsigned char>((size_t)6 * cand_bytes(nc_));   // k_step: 2 parities x 2 images; k_lag: 3 slots x 2
       ldsStep_ = step_lds_bytes(nc_, d.weights != nullptr);
       // automatic choice: the fused launch wins while a tree update is latency-bound; at large n the two-kernel path keeps
       // more waves streaming (4 per SIMD instead of 2)
@@ -1852,7 +1852,7 @@ class DevHip {
       ldsLag_ = lag_lds_bytes(nc_);
       lagOk_ = d.weights == nullptr && ldsLag_ + 40 * 1024 <= 160 * 1024 && a.gridF <= 256;
       if (lagOk_) {
-        lag_.desc = zalloc<int32_t>((size_t)2 * LD_WORDS); lag_.apply = zalloc<LagApply>(2); lag_.gtab = zalloc<uint32_t>((size_t)2 * LAG_XCD * LAG_TAB);
+        lag_.desc = zalloc<int32_t>((size_t)2 * LD_WORDS); lag_.apply = zalloc<LagApply>(2); lag_.gtab = zalloc<uint32_t>((size_t)2 * LAG_XCD * LAG_TAB * LAG_PAD);
         lag_.cells = zalloc<uint8_t>((size_t)3 * a.npad); lag_.stat = zalloc<int32_t>(LS_WORDS);
         HIP_OK(hipHostMalloc(&pinnedLag_, sizeof(int32_t) * 16, hipHostMallocDefault));
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLag_));
@@ -2230,7 +2230,10 @@ class DevHip {
   }
   void choose_path() {
     int want = pathReq_;
-    if (want == 0) want = sharing_ >= 3 ? PATH_TWO : (lagOk_ ? PATH_LAG : (fusedAuto_ ? PATH_FUSED : PATH_TWO));
+    // automatic: the fused launch while a tree update is latency-bound (few quads per thread), two kernels per tree beyond and when
+    // three or more chains share the device.  The lagged path is never chosen automatically: measured on MI355X it does not beat
+    // them (every fifth to tenth launch is a repair, and the pass of a 254-VGPR kernel is latency-bound)
+    if (want == 0) want = sharing_ >= 3 ? PATH_TWO : (fusedAuto_ ? PATH_FUSED : PATH_TWO);
     if (want == PATH_LAG && !lagOk_) want = fusedOk_ ? PATH_FUSED : PATH_TWO;
     if (want == PATH_FUSED && !fusedOk_) want = PATH_TWO;
     if (want == path_) return;
@@ -2279,6 +2282,8 @@ class DevHip {
       const double kp = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0, kc = h[8] ? 1.0 / (100.0 * (double)h[8]) : 0.0;
       fprintf(stderr, "LAGT pass workgroup 100, us from its start (avg over %llu launches): descriptor %.2f, tables staged %.2f, quads done %.2f, sums reduced %.2f, end %.2f\n",
               h[0], h[1] * kp, h[2] * kp, (double)(h[3] - h[6]) * kp, (double)(h[4] - h[6]) * kp, (double)(h[5] - h[6]) * kp);
+      fprintf(stderr, "LAGT pass, first group of the timed thread (us from workgroup start): data here %.2f, folded + stored %.2f, first level %.2f, routed %.2f, table + sums %.2f\n",
+              (double)(h[16] - h[6]) * kp, (double)(h[17] - h[6]) * kp, (double)(h[18] - h[6]) * kp, (double)(h[19] - h[6]) * kp, (double)(h[20] - h[6]) * kp);
       fprintf(stderr, "LAGT control workgroup, us from its start (avg over %llu launches): reducers done %.2f, wave 0 has the totals %.2f, decided %.2f, wave 0 at the barrier %.2f, images drawn %.2f, barrier passed %.2f, end %.2f\n",
               h[8], h[9] * kc, h[10] * kc, h[11] * kc, h[12] * kc, h[13] * kc, h[14] * kc, h[15] * kc);
       { static unsigned long long ws[256], we[256];

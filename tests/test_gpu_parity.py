@@ -39,15 +39,55 @@ def test_hip_matches_oracle(oracle_lib, hip_lib, kw):
 
 
 @pytest.mark.parametrize("n", [5000, 1003])
-@pytest.mark.parametrize("two_kernel", [False, True], ids=["fused", "two-kernel"])
-def test_bart_block_long_run(oracle_lib, hip_lib, n, two_kernel):
-    """2400 tree updates; both tree-update paths of the device layer (small n takes the fused launch by itself; the sharing hint
-    selects the two-kernel path, which large n and several chains per GPU use)."""
+@pytest.mark.parametrize("path", ["fused", "two-kernel", "lagged"])
+def test_bart_block_long_run(oracle_lib, hip_lib, n, path):
+    """2400 tree updates on each of the three tree-update paths of the device layer (s4b_set_tree_path): one fused launch per tree
+    (k_step), two kernels per tree (k_tree + k_control), and the lagged launch (k_lag: pass and decision side by side, integer
+    contingency table, repair launches when a speculated proposal image does not hold)."""
     args, _ = friedman_case(n=n, T=40, warmup=30, iter=60)
     a = run_chain(oracle_lib, "orc_", args, results_type=1)
-    b = run_chain(hip_lib, "s4b_", args, results_type=1, sharing=(4, None) if two_kernel else None)
+    b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path=path)
+    assert b["tree_path"] == (path, path)
     assert len(a["trace"]) == 40 * 60 and set(np.unique(a["trace"][:, 0])) == {0, 1, 2, 3}
     assert_chain_parity(a, b, stan=False)
+    if path == "lagged":
+        st = b["lag_stats"]
+        # every accepted birth / death costs one repair launch; a sweep is T + 2 launches plus the repairs
+        assert st["sweeps"] == 60 and st["repairs_per_sweep"] > 0
+        assert abs(st["launches_per_sweep"] - (40 + 2 + st["repairs_per_sweep"])) < 1e-9 and st["slow_passes"] == 0
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n=1003, T=50), dict(n=7, T=3, warmup=2, iter=4, ranef=False), dict(T=1, warmup=10, iter=30, ranef=False),
+                                dict(T=2, warmup=10, iter=30), dict(n_test=17), dict(slopes=True)], ids=str)
+def test_lagged_path_joint_chain(oracle_lib, hip_lib, kw):
+    """the joint (Stan + BART) chain on the lagged tree update: the same draws as the oracle"""
+    args = friedman_case(**kw)[0]
+    a = run_chain(oracle_lib, "orc_", args)
+    b = run_chain(hip_lib, "s4b_", args, tree_path="lagged")
+    assert b["tree_path"][1] == "lagged"
+    assert_chain_parity(a, b)
+
+
+@pytest.mark.parametrize("paths", [("lagged", "fused"), ("two-kernel", "lagged"), ("fused", "lagged")], ids=str)
+def test_tree_path_can_change_between_runs(oracle_lib, hip_lib, paths):
+    """every path starts a sweep from the same state (main tree arrays, residual, generator slot 0): switching between warm-up and
+    sampling gives the oracle's chain"""
+    from conftest import make_sampler
+    args, _ = friedman_case(n=3000, T=12, warmup=8, iter=16, ranef=True)
+    a = run_chain(oracle_lib, "orc_", args)
+    s = make_sampler(hip_lib, "s4b_", args)
+    try:
+        s.set_trace(True)
+        s.set_tree_path(paths[0]); w = s.run(args.warmup, True); t1 = s.get_trace()
+        s.disengage_adaptation()
+        s.set_tree_path(paths[1]); r = s.run(args.iter - args.warmup, False); t2 = s.get_trace()
+        assert s.get_tree_path() == (paths[1], paths[1])
+        assert np.array_equal(np.concatenate([t1, t2]), a["trace"])
+        np.testing.assert_allclose(r["bart"]["train"], a["sample"]["bart"]["train"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(w["stan"], a["warmup"]["stan"], rtol=1e-6, atol=1e-9)
+        assert np.array_equal(s.get_r_rng_state(), a["rng"])
+    finally:
+        s.free()
 
 
 def test_config2_shape_fixed_effects_only(oracle_lib, hip_lib):
@@ -73,12 +113,16 @@ def test_user_offset_types(oracle_lib, hip_lib):
         assert_chain_parity(run_chain(oracle_lib, "orc_", args), run_chain(hip_lib, "s4b_", args))
 
 
-def test_multi_pass_bins_and_deep_trees(oracle_lib, hip_lib):
+@pytest.mark.parametrize("path", [None, "lagged"])
+def test_multi_pass_bins_and_deep_trees(oracle_lib, hip_lib, path):
+    """> 16 leaves: several bin passes (k_step / k_tree); on the lagged path the slow (one step at a time) passes and decisions"""
     args, _ = friedman_case(n=2000, T=4, warmup=20, iter=40, ranef=False, bart_args={"base": 0.99, "power": 0.45, "k": 0.5})
     a = run_chain(oracle_lib, "orc_", args, results_type=1)
-    b = run_chain(hip_lib, "s4b_", args, results_type=1)
+    b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path=path)
     assert a["trace"][:, 4].max() > 16
     assert_chain_parity(a, b, stan=False)
+    if path == "lagged":
+        assert b["lag_stats"]["slow_passes"] > 0 and b["lag_stats"]["decisions_alone"] > 0
 
 
 def test_large_node_capacity_global_fallback(oracle_lib, hip_lib):
@@ -164,9 +208,10 @@ def test_trees_with_more_than_128_node_slots(oracle_lib, hip_lib):
     args, _ = friedman_case(n=4000, T=2, warmup=10, iter=30, ranef=False, bart_args={"base": 0.99, "power": 0.25, "k": 0.3})
     args.node_capacity = 1024
     a = run_chain(oracle_lib, "orc_", args, results_type=1)
-    b = run_chain(hip_lib, "s4b_", args, results_type=1)
     assert a["trace"][:, 4].max() > 128
-    assert_chain_parity(a, b, stan=False)
+    for path in (None, "lagged"):     # (lagged: the steps beyond the wave-register path run on the global arrays inside k_lag)
+        b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path=path)
+        assert_chain_parity(a, b, stan=False)
 
 
 @pytest.mark.parametrize("sharing", [(4, None), (None, 4), (4, 1)])

@@ -50,3 +50,17 @@ if what in ("time", "all"):
                 print(f"n={n} T={T} path={s.get_tree_path()} BART-only ms/iter {dt / 10 * 1e3:.3f} profile {prof} lag {s.get_lag_stats()}", flush=True)
             finally:
                 s.free()
+
+if what == "big":
+    from conftest import c5_case
+    for n in (4000000, 10000000):
+        args, _ = c5_case(n, P=49, T=200, n_groups=5, warmup=2, iter=4)
+        for path in ("lagged", "two-kernel", "fused"):
+            s = make_sampler(hlib, "s4b_", args)
+            try:
+                s.set_tree_path(path)
+                s.run(3, True, 1)
+                prof = s.profile_sweep(2)
+                print(f"n={n} path={s.get_tree_path()} profile {prof} lag {s.get_lag_stats()}", flush=True)
+            finally:
+                s.free()
