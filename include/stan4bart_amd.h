@@ -273,6 +273,9 @@ int S4B_FN(get_tree_path)(s4b_sampler* s, int32_t out[2]);
  * did not hold), slow (one step at a time) passes, decisions without a statistics pass beside them, host top-ups} since creation */
 int S4B_FN(get_lag_stats)(s4b_sampler* s, double out[6]);
 int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
+/* diagnostics of the one-launch O(N) sums of the Stan block (k_stan_fused): out = {evaluations, evaluations repeated in plain
+ * doubles because the fixed-point range check failed (first evaluation, rescaled response, trajectory far outside the typical set)} */
+int S4B_FN(get_fused_stats)(s4b_sampler* s, int64_t out[2]);
 
 /* NUTS totals over all transitions since creation: {transitions, sum of treedepth__, sum of n_leapfrog__, divergent transitions}
  * (the per-draw values are columns 4-6 of the stan result; the totals let a caller that keeps no per-iteration output, keep_fits =

@@ -1545,13 +1545,19 @@ __global__ __launch_bounds__(BLOCK) void k_stan_finalize(BartArrays a, StanArray
 //   DIRECT   (a leapfrog, hmc_mode 1):        e_i = e0_i - x_i'beta - z_i'b, nothing O(N) is written
 //   !DIRECT  (once per Gibbs iteration):      e_i = response_i - stanOffset_i from the BART state; e0 (and the fit) are written
 // and in both: ss = sum w e^2, X'(w e) (K columns, register accumulators), Z'(w e) (q columns).
-// Order-independent, hence deterministic, accumulation: every partial sum is split into two 64-bit fixed-point limbs
+// Order-independent, hence deterministic, accumulation: every partial sum is multiplied by a power of two chosen per group of
+// sums (|e|^2; X'e; Z'e — `scale`, from the magnitudes the previous evaluation saw), split into two 64-bit fixed-point limbs
 // (2^-20 and 2^-56 units: together finer than the rounding of the double it came from) and added with INTEGER atomics — LDS
-// histogram for Z'e, per-XCD global accumulators for everything — so there are no per-workgroup partial arrays, no second
-// kernel and no finalize pass; the host adds the eight per-XCD copies (exact integer adds) after one small device-to-host copy.
+// histogram for Z'e, per-XCD global accumulators for everything — so there are no per-workgroup partial arrays, no second kernel
+// and no finalize pass; the host adds the eight per-XCD copies (exact integer adds) after one small device-to-host copy.
+// Range: beside the sums, every group accumulates the sum of the ABSOLUTE values of what went into it (coarse units of 2^10, rounded
+// up).  While that total stays below 2^42 no partial sum anywhere (LDS slot, per-XCD copy, host total) can leave the 64-bit limb;
+// the host checks it and, when it does not hold (first evaluation, a response rescaled by orders of magnitude, a trajectory far
+// outside the typical set), evaluates the same sums in plain doubles (reduce_pipeline) and re-centres the scales.
 constexpr int SBLOCK = 256;
 constexpr int S_XCD = 8;
 constexpr int S_QMAX = 4096;          // Z'e histogram in LDS: 16 B per column (+ 8 B for b)
+constexpr double S_FX_LIMIT = 4398046511104.0;   // 2^42
 struct FxLimbs { long long hi, lo; };
 __device__ __forceinline__ FxLimbs fx_split(double v) {
   const double SH = 1048576.0, SL = 72057594037927936.0;   // 2^20, 2^56
@@ -1559,32 +1565,37 @@ __device__ __forceinline__ FxLimbs fx_split(double v) {
   FxLimbs r; r.hi = (long long)h; r.lo = (long long)rint((v - h / SH) * SL);
   return r;
 }
+__host__ __device__ static inline size_t fused_words(int M) { return (size_t)2 * M + 6; }   // limbs of the M sums + three magnitude words + three exponent words
 struct StanFusedArgs {
-  unsigned long long* acc;    // [2][S_XCD][1 + K + q][2]: accumulators of this launch (parity) and of the next one (cleared here)
-  int32_t* bad;               // [2]: a partial sum left the fixed-point range (non-finite or > 2^42 in magnitude)
+  unsigned long long* acc;    // [2][S_XCD][fused_words]: accumulators of this launch (parity) and of the next one (cleared here)
+  int32_t* bad;               // [2]: something non-finite or beyond 2^42 after scaling went into a sum
   int32_t parity, mode, wantTrain;
+  double scale[3];            // powers of two: |e|^2, X'e, Z'e
 };
 template <int KMAX, bool DIRECT>
 __global__ __launch_bounds__(SBLOCK) void k_stan_fused(BartArrays a, StanArrays s, StanFusedArgs f) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* zh = (unsigned long long*)smem;                 // [q][2]
   double* par = (double*)(smem + (size_t)s.q * 16);                   // [K + q] beta, b (DIRECT)
-  __shared__ double red[SBLOCK / 64][KMAX + 1];
+  __shared__ double red[SBLOCK / 64][KMAX + 3];
   const int K = s.K, q = s.q, M = 1 + K + q;
+  const size_t W = fused_words(M);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int j = threadIdx.x; j < 2 * q; j += SBLOCK) zh[j] = 0ull;
   if (DIRECT) for (int j = threadIdx.x; j < K + q; j += SBLOCK) par[j] = s.params[j];
   {   // clear the accumulators the NEXT evaluation uses (the host has consumed them: it synchronises on every evaluation)
-    unsigned long long* other = f.acc + (size_t)(1 - f.parity) * S_XCD * M * 2;
-    const size_t tot = (size_t)S_XCD * M * 2;
+    unsigned long long* other = f.acc + (size_t)(1 - f.parity) * S_XCD * W;
+    const size_t tot = (size_t)S_XCD * W;
     for (size_t j = (size_t)blockIdx.x * SBLOCK + threadIdx.x; j < tot; j += (size_t)gridDim.x * SBLOCK) other[j] = 0ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) f.bad[1 - f.parity] = 0;
   }
   __syncthreads();
   const ScaleState sc = *a.scale;
+  const double sS = f.scale[0], sX = f.scale[1], sZ = f.scale[2];
   double acc[KMAX + 1];
 #pragma unroll
   for (int k = 0; k <= KMAX; ++k) acc[k] = 0.0;
+  double mX = 0.0, mZ = 0.0;     // sums of absolute contributions (X'e unscaled, Z'e scaled)
   int bad = 0;
   const int64_t n = a.n;
   for (int64_t i = (int64_t)blockIdx.x * SBLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SBLOCK) {
@@ -1613,25 +1624,41 @@ __global__ __launch_bounds__(SBLOCK) void k_stan_fused(BartArrays a, StanArrays 
     const double we = a.wts ? a.wts[i] * e : e;
     acc[0] += we * e;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) if (k < K) acc[1 + k] += xv[k] * we;
+    for (int k = 0; k < KMAX; ++k) if (k < K) { const double t = xv[k] * we; acc[1 + k] += t; mX += fabs(t); }
     for (int z = e0i; z < e1i; ++z) {
-      const double c = s.w[z] * we;
-      if (!(fabs(c) < 4398046511104.0)) { bad = 1; continue; }
+      const double c = (s.w[z] * we) * sZ;
+      if (!(fabs(c) < S_FX_LIMIT)) { bad = 1; continue; }
+      mZ += fabs(c);
       const FxLimbs l = fx_split(c);
       unsigned long long* dst = zh + 2 * (size_t)s.v[z];
       atomicAdd(dst, (unsigned long long)l.hi); atomicAdd(dst + 1, (unsigned long long)l.lo);
     }
   }
-  // block reduction of ss and X'e in a fixed order, then the fixed-point hand-off
+  // block reduction of |e|^2, X'e and the magnitudes in a fixed order, then the fixed-point hand-off
 #pragma unroll
   for (int k = 0; k <= KMAX; ++k) { const double v = wave_sum(acc[k]); if (lane == 0) red[wv][k] = v; }
+  { const double v = wave_sum(mX); if (lane == 0) red[wv][KMAX + 1] = v; }
+  { const double v = wave_sum(mZ); if (lane == 0) red[wv][KMAX + 2] = v; }
   __syncthreads();
-  unsigned long long* mine = f.acc + ((size_t)f.parity * S_XCD + (blockIdx.x % S_XCD)) * M * 2;
+  unsigned long long* mine = f.acc + ((size_t)f.parity * S_XCD + (blockIdx.x % S_XCD)) * W;
   if ((int)threadIdx.x <= K) {
     const int k = threadIdx.x;
-    const double v = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
-    if (!(fabs(v) < 4398046511104.0)) bad = 1;
+    const double v = (((red[0][k] + red[1][k]) + red[2][k]) + red[3][k]) * (k == 0 ? sS : sX);
+    if (!(fabs(v) < S_FX_LIMIT)) bad = 1;
     else { const FxLimbs l = fx_split(v); atomicAdd(mine + 2 * k, (unsigned long long)l.hi); atomicAdd(mine + 2 * k + 1, (unsigned long long)l.lo); }
+  }
+  if ((int)threadIdx.x < 3) {   // magnitudes, units of 2^10, rounded up
+    const int g = threadIdx.x;
+    const int c = g == 0 ? 0 : KMAX + g;
+    double m = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+    m = g == 0 ? fabs(m) * sS : (g == 1 ? m * sX : m);
+    if (!(m < 4.0e18)) bad = 1;
+    else {
+      atomicAdd(mine + 2 * (size_t)M + g, (unsigned long long)(m * 0.0009765625) + 1ull);
+      // binary exponent of the largest workgroup magnitude of the group (offset 4000; 0 = nothing but zeros went in): what the
+      // host centres the scales on, and how it notices magnitudes that have sunk towards the resolution of the low limb
+      if (m > 0.0) atomicMax(mine + 2 * (size_t)M + 3 + g, (unsigned long long)(ilogb(m) + 4000));
+    }
   }
   for (int j = threadIdx.x; j < 2 * q; j += SBLOCK) { const unsigned long long v = zh[j]; if (v) atomicAdd(mine + 2 * (1 + K) + j, v); }
   if (bad) atomicOr(f.bad + f.parity, 1);
@@ -1895,8 +1922,8 @@ class DevHip {
       stanFused_ = K_ <= 16 && q_ <= S_QMAX;
       if (const char* f = getenv("S4B_STAN_FUSED")) stanFused_ = stanFused_ && atoi(f) != 0;
       if (stanFused_) {
-        fusedAcc_ = zalloc<unsigned long long>((size_t)2 * S_XCD * M * 2); fusedBad_ = zalloc<int32_t>(2);
-        HIP_OK(hipHostMalloc(&pinnedAcc_, sizeof(unsigned long long) * (S_XCD * M * 2 + 8), hipHostMallocDefault));
+        fusedAcc_ = zalloc<unsigned long long>((size_t)2 * S_XCD * fused_words((int)M)); fusedBad_ = zalloc<int32_t>(2);
+        HIP_OK(hipHostMalloc(&pinnedAcc_, sizeof(unsigned long long) * (S_XCD * fused_words((int)M) + 8), hipHostMallocDefault));
         if (fusedLds_ > 48 * 1024) {
           const void* fns[8] = {reinterpret_cast<const void*>(k_stan_fused<2, true>), reinterpret_cast<const void*>(k_stan_fused<2, false>),
                                 reinterpret_cast<const void*>(k_stan_fused<4, true>), reinterpret_cast<const void*>(k_stan_fused<4, false>),
@@ -2385,15 +2412,29 @@ class DevHip {
 
   // ---- Stan inputs
   void stan_inputs(int mode, bool wantTrain, double* cX, double* cZ, double* s0, double* trainOut) {
-    if (stanFused_) { launch_stan_fused(mode, wantTrain ? 1 : 0, false); fetch_fused(cX, cZ, s0); }
-    else { reduce_pipeline(mode, wantTrain ? 1 : 0, 0); fetch_out(cX, cZ, s0); }
+    if (stanFused_) {
+      launch_stan_fused(mode, wantTrain ? 1 : 0, false);
+      if (!fetch_fused(cX, cZ, s0)) { reduce_pipeline(mode, wantTrain ? 1 : 0, 0); fetch_out(cX, cZ, s0); recentre_scales(cX, cZ, *s0); }
+    } else { reduce_pipeline(mode, wantTrain ? 1 : 0, 0); fetch_out(cX, cZ, s0); }
     if (wantTrain && trainOut) { download(trainOut, s_.train, (size_t)n_); sync(); }
   }
   double leapfrog_sums(const double* beta, const double* b, double* gX, double* gZ) {
     push_params(beta, b);
     double ss;
-    if (stanFused_) { launch_stan_fused(0, 0, true); fetch_fused(gX, gZ, &ss); }
-    else { reduce_pipeline(0, 0, 1); fetch_out(gX, gZ, &ss); }
+    if (stanFused_) {
+      launch_stan_fused(0, 0, true);
+      if (!fetch_fused(gX, gZ, &ss)) { reduce_pipeline(0, 0, 1); fetch_out(gX, gZ, &ss); recentre_scales(gX, gZ, ss); }
+#ifdef S4B_FX_DEBUG
+      else {
+        std::vector<double> rX((size_t)K_ + 1), rZ((size_t)q_ + 1); double rs;
+        reduce_pipeline(0, 0, 1); fetch_out(rX.data(), rZ.data(), &rs);
+        double worst = std::fabs(rs - ss) / (std::fabs(rs) + 1e-300);
+        for (int k = 0; k < K_; ++k) worst = std::max(worst, std::fabs(rX[k] - gX[k]) / (std::fabs(rX[k]) + 1e-12));
+        for (int j = 0; j < q_; ++j) worst = std::max(worst, std::fabs(rZ[j] - gZ[j]) / (std::fabs(rZ[j]) + 1e-12));
+        if (worst > 1e-9) fprintf(stderr, "FXDBG eval %lld: worst rel diff %.3e (ss %.17g vs %.17g) exps %d %d %d\n", (long long)fusedEvals_, worst, ss, rs, fxExp_[0], fxExp_[1], fxExp_[2]);
+      }
+#endif
+    } else { reduce_pipeline(0, 0, 1); fetch_out(gX, gZ, &ss); }
     return ss;
   }
   // one launch per evaluation (k_stan_fused)
@@ -2403,6 +2444,7 @@ class DevHip {
   }
   void launch_stan_fused(int mode, int wantTrain, bool direct) {
     StanFusedArgs f; f.acc = fusedAcc_; f.bad = fusedBad_; f.parity = fusedParity_; f.mode = mode; f.wantTrain = wantTrain;
+    for (int g = 0; g < 3; ++g) f.scale[g] = std::ldexp(1.0, fxExp_[g]);
     const int grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n_ + SBLOCK - 1) / SBLOCK));
     if (K_ <= 2) launch_stan_fused_k<2>(f, direct, fusedLds_, grid);
     else if (K_ <= 4) launch_stan_fused_k<4>(f, direct, fusedLds_, grid);
@@ -2410,24 +2452,76 @@ class DevHip {
     else launch_stan_fused_k<16>(f, direct, fusedLds_, grid);
     ++launches_;
   }
-  void fetch_fused(double* cX, double* cZ, double* s0) {
-    const size_t M = (size_t)(1 + K_ + q_);
-    HIP_OK(hipMemcpyAsync(pinnedAcc_, fusedAcc_ + (size_t)fusedParity_ * S_XCD * M * 2, S_XCD * M * 16, hipMemcpyDeviceToHost, stream_));
-    HIP_OK(hipMemcpyAsync(pinnedAcc_ + S_XCD * M * 2, fusedBad_ + fusedParity_, 4, hipMemcpyDeviceToHost, stream_));
+  // false: the evaluation cannot be trusted (see k_stan_fused) — the caller repeats it in plain doubles
+  bool fetch_fused(double* cX, double* cZ, double* s0) {
+    const size_t M = (size_t)(1 + K_ + q_), W = fused_words((int)M);
+    HIP_OK(hipMemcpyAsync(pinnedAcc_, fusedAcc_ + (size_t)fusedParity_ * S_XCD * W, S_XCD * W * 8, hipMemcpyDeviceToHost, stream_));
+    HIP_OK(hipMemcpyAsync(pinnedAcc_ + S_XCD * W, fusedBad_ + fusedParity_, 4, hipMemcpyDeviceToHost, stream_));
     sync();
     fusedParity_ ^= 1;
-    const bool bad = (*(const int32_t*)(pinnedAcc_ + S_XCD * M * 2)) != 0;
-    auto val = [&](size_t k) {
+    bool bad = (*(const int32_t*)(pinnedAcc_ + S_XCD * W)) != 0;
+    // the magnitudes: sums of absolute contributions in units of 2^10 (after scaling); below 2^32 no limb can have wrapped
+    unsigned long long mag[3] = {0, 0, 0};
+    for (int x = 0; x < S_XCD; ++x) for (int g = 0; g < 3; ++g) {
+      const unsigned long long m = pinnedAcc_[(size_t)x * W + 2 * M + g];
+      if (m > (1ull << 40)) bad = true;
+      mag[g] += m;
+    }
+    for (int g = 0; g < 3; ++g) if (mag[g] >= (1ull << 32)) bad = true;
+    int ex[3]; bool seen[3];
+    for (int g = 0; g < 3; ++g) {
+      unsigned long long m = 0;
+      for (int x = 0; x < S_XCD; ++x) m = std::max(m, pinnedAcc_[(size_t)x * W + 2 * M + 3 + g]);
+      seen[g] = m != 0; ex[g] = (int)m - 4000;
+      if (seen[g] && ex[g] < 4) bad = true;         // the scale is far too small for what is being summed now: resolution lost
+    }
+    ++fusedEvals_;
+#ifdef S4B_FX_DEBUG
+    if (bad) fprintf(stderr, "FXDBG eval %lld bad: flag %d mag %llu %llu %llu ex %d %d %d seen %d%d%d exps %d %d %d\n", (long long)fusedEvals_, (int)*(const int32_t*)(pinnedAcc_ + S_XCD * W),
+                     mag[0], mag[1], mag[2], ex[0], ex[1], ex[2], (int)seen[0], (int)seen[1], (int)seen[2], fxExp_[0], fxExp_[1], fxExp_[2]);
+#endif
+    if (bad) {
+      ++fusedFallbacks_;
+      const bool overflow = (*(const int32_t*)(pinnedAcc_ + S_XCD * W)) != 0 || mag[0] >= (1ull << 32) || mag[1] >= (1ull << 32) || mag[2] >= (1ull << 32);
+      // only the resolution check failed: the exponents are a valid measurement — centre on them, the caller repeats this one in doubles
+      if (!overflow) { for (int g = 0; g < 3; ++g) if (seen[g]) fxExp_[g] = std::max(-900, std::min(900, fxExp_[g] + (22 - ex[g]))); fxTinyFail_ = true; }
+      else fxTinyFail_ = false;
+      return false;
+    }
+    const double inv[3] = {std::ldexp(1.0, -fxExp_[0]), std::ldexp(1.0, -fxExp_[1]), std::ldexp(1.0, -fxExp_[2])};
+    auto val = [&](size_t k, int g) {
       long long hi = 0, lo = 0;
-      for (int x = 0; x < S_XCD; ++x) { hi += (long long)pinnedAcc_[((size_t)x * M + k) * 2]; lo += (long long)pinnedAcc_[((size_t)x * M + k) * 2 + 1]; }
-      return (double)hi / 1048576.0 + (double)lo / 72057594037927936.0;
+      for (int x = 0; x < S_XCD; ++x) { hi += (long long)pinnedAcc_[(size_t)x * W + 2 * k]; lo += (long long)pinnedAcc_[(size_t)x * W + 2 * k + 1]; }
+      return ((double)hi / 1048576.0 + (double)lo / 72057594037927936.0) * inv[g];
     };
-    // a sum that left the fixed-point range (non-finite or astronomically large residuals: a trajectory far outside the typical set)
-    // is reported as a non-finite likelihood, which NUTS treats like the reference treats an exception: V = +inf (base_hamiltonian.hpp:61-70)
-    *s0 = bad ? std::numeric_limits<double>::infinity() : val(0);
-    for (int k = 0; k < K_; ++k) cX[k] = bad ? 0.0 : val((size_t)1 + k);
-    for (int j = 0; j < q_; ++j) cZ[j] = bad ? 0.0 : val((size_t)1 + K_ + j);
+    *s0 = val(0, 0);
+    for (int k = 0; k < K_; ++k) cX[k] = val((size_t)1 + k, 1);
+    for (int j = 0; j < q_; ++j) cZ[j] = val((size_t)1 + K_ + j, 2);
+    // keep the largest workgroup magnitude of every group near 2^22 after scaling: with at most 2^10 workgroups the magnitude total
+    // stays below 2^32 + 10 = 2^42 with 2^10 to spare, and the low limb resolves 2^-78 of a workgroup's contribution
+    for (int g = 0; g < 3; ++g) if (seen[g]) fxExp_[g] = std::max(-900, std::min(900, fxExp_[g] + (22 - ex[g])));
+    return true;
   }
+  // after an evaluation in plain doubles that an OVERFLOW of the fixed-point range made necessary: smaller scales, from the totals
+  // themselves where they are finite (a first guess; the next fused evaluation that succeeds centres them on the magnitudes).
+  // Consecutive failures shrink them further.
+  void recentre_scales(const double* cX, const double* cZ, double ss) {
+    if (fxTinyFail_) return;        // (already centred on the measured exponents)
+    double mx = 0.0, mz = 0.0;
+    for (int k = 0; k < K_; ++k) if (std::isfinite(cX[k])) mx = std::max(mx, std::fabs(cX[k]));
+    for (int j = 0; j < q_; ++j) if (std::isfinite(cZ[j])) mz = std::max(mz, std::fabs(cZ[j]));
+    const double tot[3] = {std::isfinite(ss) ? std::fabs(ss) : 0.0, mx, mz};
+    // a single evaluation out of range (one point of a diverging trajectory, the random initial values) leaves the scales alone: the
+    // next one is usually back in range; only a second failure in a row moves them
+    if (fxLastBad_ == fusedEvals_ - 1)
+      for (int g = 0; g < 3; ++g) {
+        int want = fxExp_[g] - 10;
+        if (tot[g] > 0.0) want = std::min(want, 20 - std::ilogb(tot[g]));
+        fxExp_[g] = std::max(-900, std::min(900, want));
+      }
+    fxLastBad_ = fusedEvals_;
+  }
+  void fused_stats(int64_t out[2]) const { out[0] = fusedEvals_; out[1] = fusedFallbacks_; }
 
   // HIP-event timing of the per-leapfrog O(N) sums (hmc_mode 1 path: e = e0 - X beta - Z b, |e|^2, X'e, Z'e) on the
   // sampler's stream.  out: [0] us per evaluation, kernels only; [1] us per evaluation including the result fetch;
@@ -2538,6 +2632,7 @@ class DevHip {
   double* pinned_ = nullptr; double* testOut_ = nullptr; double* latX_ = nullptr;
   unsigned long long* fusedAcc_ = nullptr; int32_t* fusedBad_ = nullptr; unsigned long long* pinnedAcc_ = nullptr;
   size_t fusedLds_ = 0; int fusedParity_ = 0; bool stanFused_ = false;
+  int fxExp_[3] = {0, 0, 0}; int64_t fusedEvals_ = 0, fusedFallbacks_ = 0, fxLastBad_ = -2; bool fxTinyFail_ = false;
   int64_t launches_ = 0;
 };
 

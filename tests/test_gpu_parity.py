@@ -301,3 +301,37 @@ def test_probit_latents_long_stream(oracle_lib, hip_lib):
     a = run_chain(oracle_lib, "orc_", args, results_type=1)
     b = run_chain(hip_lib, "s4b_", args, results_type=1)
     assert_chain_parity(a, b, stan=False)
+
+
+@pytest.mark.parametrize("scale", [1e5, 1e-6, 3e9, 1.0])
+@pytest.mark.parametrize("hmc_mode", [0, 1])
+def test_response_scale_extremes(oracle_lib, hip_lib, scale, hmc_mode):
+    """The O(N) sums of the Stan block are accumulated in fixed point (k_stan_fused): the representation follows the magnitude of
+    what is summed, and an evaluation whose range / resolution check fails is repeated in plain doubles.  Responses of order 1e5
+    (sum of squares ~ 1e13 at n = 1.5e3: beyond the unscaled 2^43 range), 1e-6 (far below the unscaled 2^-56 resolution) and 3e9
+    give the oracle's chain; once the chain has left its random initial values the fallback is the exception."""
+    from conftest import make_sampler
+    from stan4bart_amd import GroupTerm, make_sampler_args
+    _, d = friedman_case(n=1500, T=10, warmup=7, iter=13, slopes=True)
+    x = d["x"]
+    xb = x[:, [j for j in range(10) if j != 3]]
+    y = d["y"] * scale
+
+    def mk(**extra):
+        return make_sampler_args(y, xb, X=np.column_stack([x[:, 3], d["z"]]), groups=[GroupTerm(d["g1"], x[:, 3], "g.1"), GroupTerm(d["g2"], None, "g.2")],
+                                 iter=13, warmup=7, bart_args={"n.trees": 10}, **extra)
+    a = run_chain(oracle_lib, "orc_", mk())
+    b = run_chain(hip_lib, "s4b_", mk(stan_args={"hmc_mode": hmc_mode}))
+    assert_chain_parity(a, b, rtol=1e-6, atol=1e-9 * scale)
+    # a longer chain: the sampling phase runs on the fixed-point path
+    args = mk(stan_args={"hmc_mode": hmc_mode})
+    s = make_sampler(hip_lib, "s4b_", args)
+    try:
+        s.run(40, True, 0)
+        e0, f0 = s.get_fused_stats()
+        s.disengage_adaptation()
+        s.run(40, False, 0)
+        e1, f1 = s.get_fused_stats()
+    finally:
+        s.free()
+    assert e1 - e0 >= 40 and f1 - f0 <= 2 + (e1 - e0) // 50, (e0, f0, e1, f1)
