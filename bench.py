@@ -13,13 +13,15 @@ A "step" is one Gibbs iteration = one NUTS transition of the Stan block + one BA
 What is timed is a RUNNING chain, in the reference's phase order (R/stan4bart_fit.R:49-51: warm-up, disengage adaptation,
 sample): `--burn-in` untimed warm-up iterations with adaptation engaged (step size, metric windows) bring the chain to its
 stationary regime, adaptation is disengaged, then W untimed and exactly K timed iterations of the SAMPLING phase follow.
-Leapfrogs per transition and mean tree depth of the timed iterations are reported in `config` (on this workload the adapted
-chain needs ~10 leapfrogs per transition, tree depth 3); the warm-up phase's own rate is `warmup_phase_iters_per_sec`.
+Leapfrogs per transition and mean tree depth of the timed iterations are reported in `config`.
 
 Extra objects on the same JSON line:
-  roofline      dominant kernel of the sweep, HIP-event timing on the sampler's own stream, against 8 TB/s HBM
-  cpu_baseline  the CPU oracle (oracle/, "port") timed on this box's host, rank 0 at N = 1 only, on the same workload
-  extra_configs BASELINE configs 1 and 2 (CPU port for both, the HIP path for config 2), small and quick
+  roofline            dominant kernel of the sweep, HIP-event timing on the sampler's own stream, against 8 TB/s HBM
+  per_chain_hmc_mode1 the same chain continued for K more timed iterations with one O(N) device evaluation per leapfrog
+                      (the reference's cost model); the headline uses sufficient statistics gathered once per iteration
+  cpu_baseline        the CPU oracle (oracle/, "port") timed on this box's host, rank 0 at N = 1 only, on the same workload,
+                      started from the GPU chain's state after the burn-in (same regime: same leapfrogs per transition)
+  extra_configs       BASELINE configs 1 and 2 (CPU port for both, the HIP path for config 2), small and quick
 """
 from __future__ import annotations
 
@@ -28,6 +30,7 @@ import ctypes
 import json
 import os
 import shutil
+import subprocess
 import sys
 import time
 
@@ -37,6 +40,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+DOMINANT = {"fused": "k_step", "two-kernel": "k_tree", "lagged": "k_lag"}
+
+
+def pin_rank_to_cores(local_rank: int, ranks_on_node: int):
+    """One chain = one host thread (NUTS control flow, launches).  N ranks on one socket otherwise migrate across each other's
+    cores: give every rank a disjoint, contiguous core set.  Returns the cores this process may run on."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        if ranks_on_node <= 1 or len(cores) < ranks_on_node:
+            return cores
+        per = len(cores) // ranks_on_node
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (AttributeError, OSError):
+        return []
 
 
 def friedman_design(n, p, rank, world, barrier):
@@ -61,14 +80,37 @@ def friedman_design(n, p, rank, world, barrier):
     return d
 
 
-def case_from_design(d, p, trees, device, warmup, iters, ranef=True, keep_fits=False):
+def case_from_design(d, p, trees, device, warmup, iters, ranef=True, keep_fits=False, hmc_mode=0):
     from stan4bart_amd import GroupTerm, make_sampler_args
     x = d["x"]
     xb = np.asfortranarray(x[:, [j for j in range(p) if j != 3]])
     X = np.column_stack([x[:, 3], d["z"]])
     groups = [GroupTerm(d["g1"], x[:, 3], "g.1"), GroupTerm(d["g2"], None, "g.2")] if ranef else []
     return make_sampler_args(d["y"], xb, X=X, groups=groups, iter=iters, warmup=warmup, keep_fits=keep_fits,
-                             bart_args={"n.trees": trees}, device=device)
+                             bart_args={"n.trees": trees}, device=device, stan_args={"hmc_mode": hmc_mode})
+
+
+def sweep_roofline(prof, path, n, trees, lag):
+    """Roofline record of the dominant kernel of one sweep.  Algorithmic bytes of a tree update: R read 8 + R write 8 + leaf id of
+    the finished tree 2 + leaf id of the tree whose statistics are gathered 2 + binned predictor 2 = 22 B per observation."""
+    per_launch = 22.0 * n
+    rec = {"bound": "hbm", "kernel": DOMINANT[path], "tree_path": path, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "avg_launch_us": prof["stats_us"], "algorithmic_bytes_per_launch": per_launch,
+           "timing": "HIP events around every launch on the sampler's stream (adds ~2 us per launch; profiles/ has rocprofv3)",
+           "sweep_wall_us": prof["sweep_wall_us"], "tree_update_wall_us": prof["sweep_wall_us"] / trees,
+           "achieved_GBs_whole_sweep": per_launch * trees / (prof["sweep_wall_us"] * 1e-6) / 1e9}
+    rec["achieved"] = per_launch / (prof["stats_us"] * 1e-6) / 1e9
+    rec["frac"] = rec["achieved"] / HBM_PEAK_GBS
+    if path == "two-kernel":
+        rec["separate_control_kernel_us"] = prof["control_us"]
+        rec["last_launch_of_sweep_us"] = prof["apply_us"]
+    elif path == "fused":
+        rec["last_launch_of_sweep_us"] = prof["apply_us"]
+    else:   # lagged: launches per sweep and repairs per sweep come back in the control / apply slots
+        rec["launches_per_sweep"] = prof["control_us"]
+        rec["repair_launches_per_sweep"] = prof["apply_us"]
+        rec["lag_stats"] = lag
+    return rec
 
 
 def target_roofline_leg(lib, n, p, trees, device, sweeps):
@@ -76,7 +118,7 @@ def target_roofline_leg(lib, n, p, trees, device, sweeps):
     the same dominant kernel there too, live, on a BART-sized case (Friedman surface, fixed effects X4 + z, numpy's
     generator for the 5e8 uniforms — the R-compatible stream would take minutes on the host and the sweep's cost does
     not depend on which generator made x)."""
-    from stan4bart_amd import RRng, make_sampler_args
+    from stan4bart_amd import GroupTerm, RRng, make_sampler_args
     from stan4bart_amd.abi import Sampler
     g = np.random.default_rng(99)
     xb = np.empty((n, p - 1), order="F")
@@ -84,7 +126,6 @@ def target_roofline_leg(lib, n, p, trees, device, sweeps):
         xb[:, j] = g.random(n)
     x4 = g.random(n)
     z = (g.random(n) < 0.2).astype(np.float64)
-    from stan4bart_amd import GroupTerm
     g1, g2 = g.integers(1, 6, size=n), g.integers(1, 9, size=n)
     b1 = g.standard_normal((5, 2)) @ np.linalg.cholesky(np.array([[2.25, 0.2], [0.2, 1.0]])).T
     y = (10.0 * np.sin(np.pi * xb[:, 0] * xb[:, 1]) + 20.0 * (xb[:, 2] - 0.5) ** 2 + 5.0 * xb[:, 3] + 10.0 * x4 + 5.0 * z
@@ -96,24 +137,20 @@ def target_roofline_leg(lib, n, p, trees, device, sweeps):
     args.seed = int(rng.sample_int(2147483647, 1)[0])
     s = Sampler(lib, "s4b_", args, rng.state)
     s.run(2, True, 0)
+    path = s.get_tree_path()[1]
     prof = s.profile_sweep(sweeps)
     lf = s.profile_leapfrog(10)
+    rec = sweep_roofline(prof, path, n, trees, s.get_lag_stats())
     s.free()
-    fused = prof["control_us"] == 0.0
-    achieved = 22.0 * n / (prof["stats_us"] * 1e-6) / 1e9
-    return {"workload": f"Friedman n={n}, p={p}, ntree={trees} (north_star roofline target config)",
-            "kernel": "k_step" if fused else "k_tree", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "avg_launch_us": prof["stats_us"], "k_control_us": prof["control_us"],
-            "algorithmic_bytes_per_launch": 22.0 * n, "sweep_wall_us": prof["sweep_wall_us"],
-            "achieved_GBs_whole_sweep": 22.0 * n * trees / (prof["sweep_wall_us"] * 1e-6) / 1e9,
-            "hmc": {"kernel": "k_stan_fused (direct), K=2, z=3", "bound": "hbm", "achieved": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                    "avg_eval_us": lf["kernels_us"], "avg_eval_us_with_result_fetch": lf["with_fetch_us"], "launches_per_eval": lf["launches"],
-                    "algorithmic_bytes_per_eval": lf["algorithmic_bytes"]}}
+    rec["workload"] = f"Friedman n={n}, p={p}, ntree={trees} (north_star roofline target config)"
+    rec["hmc"] = {"kernel": "k_stan_fused (direct), K=2, z=3", "bound": "hbm", "achieved": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                  "avg_eval_us": lf["kernels_us"], "avg_eval_us_with_result_fetch": lf["with_fetch_us"], "launches_per_eval": lf["launches"],
+                  "algorithmic_bytes_per_eval": lf["algorithmic_bytes"]}
+    return rec
 
 
 def oracle_lib():
-    import subprocess
     so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
     if not os.path.exists(so):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -136,48 +173,108 @@ def time_chain(lib, prefix, args, seed, warm, iters):
     return iters / dt, dt
 
 
+def cpu_baseline_from_state(olib, args, state, iters):
+    """The CPU oracle on the same workload, in the same regime: its chain state is REPLACED by the GPU chain's state after the
+    burn-in (adapted step size and metric, trees, residual), adaptation disengaged, then `iters` sampling iterations are timed.
+    Returns the record's value fields and the leapfrogs it needed."""
+    from stan4bart_amd import RRng
+    from stan4bart_amd.abi import Sampler
+    rng = RRng(12345)
+    args.seed = int(rng.sample_int(2147483647, 1)[0])
+    s = Sampler(olib, "orc_", args, rng.state)
+    try:
+        s.disengage_adaptation()
+        s.set_state(state)
+        n0 = s.get_nuts_stats()
+        t0 = time.perf_counter()
+        s.run(iters, False, 0)
+        dt = time.perf_counter() - t0
+        n1 = s.get_nuts_stats()
+    finally:
+        s.free()
+    return iters / dt, dt, (n1["sum_n_leapfrog"] - n0["sum_n_leapfrog"]) / iters
+
+
+def reference_r_leg(n, p, trees, iters):
+    """bench/reference_cpu.R: the installed CRAN package on this box's host cores, when R and the package exist."""
+    rscript = shutil.which("Rscript")
+    if rscript is None:
+        return {"status": "Rscript not found on this box: the CPU figure is the repo's C++ restatement (oracle/), not vdorie/stan4bart itself",
+                "script": "bench/reference_cpu.R"}
+    try:
+        out = subprocess.run([rscript, os.path.join(ROOT, "bench", "reference_cpu.R"), str(n), str(p), str(trees), str(iters)],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3600)
+    except subprocess.TimeoutExpired:
+        return {"status": "bench/reference_cpu.R timed out after 3600 s", "script": "bench/reference_cpu.R"}
+    for line in out.stdout.splitlines()[::-1]:
+        if line.startswith("{"):
+            try:
+                rec = json.loads(line)
+                rec["script"] = "bench/reference_cpu.R"
+                return rec
+            except ValueError:
+                pass
+    return {"status": "bench/reference_cpu.R did not report (is the stan4bart package installed?): " + out.stderr.strip()[-300:], "script": "bench/reference_cpu.R"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--burn-in", type=int, default=150, help="untimed warm-up-phase iterations before the W + K sampling-phase iterations")
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--n", "--num-obs", dest="n", type=int, default=1_000_000)   # (--num-obs: torchrun's own parser trips over a bare --n)
     ap.add_argument("--p", type=int, default=50)
     ap.add_argument("--trees", type=int, default=200)
-    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
+    ap.add_argument("--no-hmc-mode1", action="store_true")
     ap.add_argument("--profile-sweeps", type=int, default=2)
+    ap.add_argument("--tree-path", default="auto", choices=["auto", "two-kernel", "fused", "lagged"])
     ap.add_argument("--target-n", type=int, default=10_000_000,
                     help="also measure the sweep kernel at north_star's roofline-target size (0 = skip; N = 1 only)")
+    ap.add_argument("--emul", action="store_true",
+                    help="TEST ONLY (pytest -m 'not gpu'): run the N-rank plumbing of this script over the CPU emulation of the device layer "
+                         "(tests/emul) and gloo; prints a line whose numbers mean nothing")
     a = ap.parse_args()
     t_start = time.perf_counter()
 
     import torch
     from stan4bart_amd import RRng
     from stan4bart_amd.abi import Sampler
-    from stan4bart_amd._lib import load_library
     from stan4bart_amd.fit import chain_seeds
-    from stan4bart_amd.parallel import all_gather_array, init_process_group
+    from stan4bart_amd.parallel import all_gather_array, dist_env, init_process_group
 
     # S4B_BENCH_BACKEND=gloo + S4B_BENCH_ONE_DEVICE=1: rehearsal of the N-rank path on a single-GPU box (all ranks share
     # device 0, the collectives run over gloo); the driver's real runs use the default: one GPU per rank, RCCL
-    rank, local_rank, world = init_process_group(os.environ.get("S4B_BENCH_BACKEND"))
-    if os.environ.get("S4B_BENCH_ONE_DEVICE"):
+    rank0, local0, world0 = dist_env()
+    if world0 != a.gpus and world0 > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world0}")
+    one_device = bool(os.environ.get("S4B_BENCH_ONE_DEVICE"))
+    if not a.emul:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        if not one_device and torch.cuda.device_count() < world0:
+            raise SystemExit(f"WORLD_SIZE={world0} ranks but only {torch.cuda.device_count()} GPU(s) are visible: one chain per GPU needs one GPU per rank")
+    cores = pin_rank_to_cores(local0, world0)       # before the runtimes start their helper threads
+    rank, local_rank, world = init_process_group("gloo" if a.emul else os.environ.get("S4B_BENCH_BACKEND"))
+    if one_device or a.emul:
         local_rank = 0
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    lib = load_library()
+    if a.emul:
+        lib, prefix = ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "_build", "libs4b_emul.so")), "emu_"
+    else:
+        from stan4bart_amd._lib import load_library
+        torch.cuda.set_device(local_rank)
+        lib, prefix = load_library(), "s4b_"
 
     def barrier():
-        torch.cuda.synchronize()
+        if not a.emul:
+            torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if not a.emul:
+            torch.cuda.synchronize()
 
     d = friedman_design(a.n, a.p, rank, world, barrier)
     t_design = time.perf_counter()
@@ -186,7 +283,8 @@ def main():
     args = case_from_design(d, a.p, a.trees, local_rank, a.burn_in, total)
     rng = RRng(int(chain_seeds(20260101, max(1, world))[rank]))
     args.seed = int(rng.sample_int(2147483647, 1)[0])
-    sampler = Sampler(lib, "s4b_", args, rng.state)     # uploads everything: inputs are HBM-resident from here on
+    sampler = Sampler(lib, prefix, args, rng.state)     # uploads everything: inputs are HBM-resident from here on
+    sampler.set_tree_path(a.tree_path)
     t_created = time.perf_counter()
     # ---- phase 1 (untimed for the metric): warm-up with adaptation engaged, to the stationary regime
     warm_rate = None
@@ -198,123 +296,153 @@ def main():
     # ---- phase 2: sampling.  W untimed, then exactly K timed Gibbs iterations
     if a.warmup > 0:
         sampler.run(a.warmup, False, 0)
+    state_after_burn_in = sampler.get_state() if (rank == 0 and world == 1 and not a.no_cpu_baseline and not a.emul) else None
     barrier()
     c0, s0 = sampler.get_counters(), sampler.get_nuts_stats()
     t0 = time.perf_counter()
     out = sampler.run(a.steps, False, 0)                # (run() returns synchronised)
-    torch.cuda.synchronize()
+    if not a.emul:
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     c1, s1 = sampler.get_counters(), sampler.get_nuts_stats()
     barrier()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt_max = float(t.item())
-    else:
-        dt_max = dt
-    # the only collective: chain summaries (last sigma, per-rank set-up seconds)
-    summ = all_gather_array(np.array([float(out["bart"]["sigma"][-1]), t_design - t_start, t_created - t_design]))
+    hmc_mode = sampler.get_hmc_mode()
+    tree_path = sampler.get_tree_path()[1] if not a.emul else "emulation"
+    # ---- the same chain with one O(N) device evaluation per leapfrog (the reference's cost model), W untimed + K timed
+    dt1 = None
+    if not a.no_hmc_mode1 and not a.emul:
+        sampler.set_hmc_mode(1)
+        if a.warmup > 0:
+            sampler.run(a.warmup, False, 0)
+        barrier()
+        m0 = sampler.get_nuts_stats()
+        t0 = time.perf_counter()
+        sampler.run(a.steps, False, 0)
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t0
+        m1 = sampler.get_nuts_stats()
+        barrier()
+        sampler.set_hmc_mode(hmc_mode)
 
-    prof = sampler.profile_sweep(a.profile_sweeps) if rank == 0 else None
-    lf = sampler.profile_leapfrog(20) if rank == 0 else None
-    probe = None
-    if rank == 0:   # measured streaming ceiling of this device (read-only and in-place update over 1 GB)
-        po = (ctypes.c_double * 4)()
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+    dt_max = max_over_ranks(dt)
+    dt1_max = max_over_ranks(dt1) if dt1 is not None else None
+    # the only collective: chain summaries (last sigma, per-rank set-up seconds, per-rank timed seconds)
+    summ = all_gather_array(np.array([float(out["bart"]["sigma"][-1]), t_design - t_start, t_created - t_design, dt, float(len(cores))]))
+
+    prof = lf = probe = lag = None
+    if rank == 0 and not a.emul:
+        lag = sampler.get_lag_stats()
+        prof = sampler.profile_sweep(a.profile_sweeps)
+        lf = sampler.profile_leapfrog(20)
+        po = (ctypes.c_double * 4)()   # measured streaming ceiling of this device (read-only and in-place update over 1 GB)
         lib.s4b_stream_probe.restype = ctypes.c_int
         if lib.s4b_stream_probe(ctypes.c_int32(local_rank), ctypes.c_int64(1 << 27), ctypes.c_int32(5), po) == 0:
             probe = {"read_GBs": po[0], "update_in_place_GBs": po[1]}
+    fused_stats = sampler.get_fused_stats()
     sampler.free()
-    del args
     target = None
-    if world == 1 and a.target_n > 0 and a.target_n != a.n:
+    if world == 1 and a.target_n > 0 and a.target_n != a.n and not a.emul:
         target = target_roofline_leg(lib, a.target_n, a.p, a.trees, local_rank, a.profile_sweeps)
 
     if rank == 0:
         n = a.n
         per_chain = a.steps / dt_max
         trans = max(1, s1["transitions"] - s0["transitions"])
-        fused = prof["control_us"] == 0.0
-        # dominant kernel of the sweep and its algorithmic bytes per launch (DESIGN.md "Roofline accounting"): the O(N) part of
-        # one tree update (finish tree t-1 + statistics of tree t):
-        # R read 8 + R write 8 + leaf(t-1) read 2 + leaf(t) read 2 + binned predictor 2 = 22 B per observation.
-        # fused path: k_step is the WHOLE tree update (control code included); two-kernel path: k_tree, with k_control beside it
-        dom = "k_step" if fused else "k_tree"
-        dom_us, dom_bytes = prof["stats_us"], 22.0 * n
-        achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-        # HBM traffic of the tree kernel: REPLAYED from the PMC passes committed under profiles/ (rocprofv3 cannot wrap this
-        # process from inside; collected on this command line by tools/profile_round.sh, see profiles/pmc_traffic.json)
-        traffic, traffic_note = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pj = json.load(f)
-            traffic = pj.get(str(n), {}).get("bytes_per_launch")
-            traffic_note = "replayed from profiles/pmc_traffic.json (" + str(pj.get(str(n), {}).get("kernel", "tree kernel")) + "), not measured in this run"
-        except (OSError, ValueError):
-            pass
+        per_rank = [a.steps / float(s[3]) for s in summ]
         rec = {
             "metric": "gibbs_iters_per_sec", "value": per_chain * world, "unit": "Gibbs iterations/s (all chains)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt_max / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "per_chain": per_chain,
+            "per_chain": per_chain, "per_chain_by_rank": per_rank,
             "phase_timed": f"sampling (after {a.burn_in} untimed warm-up iterations with adaptation, disengage, {a.warmup} untimed sampling iterations)",
             "warmup_phase_iters_per_sec": warm_rate,
             "config": {"workload": f"Friedman n={n}, p={a.p}, ntree={a.trees}, (1+X4|g.1)+(1|g.2), one chain per GPU"
                                    + (" (BASELINE config 3)" if (n, a.p, a.trees) == (1_000_000, 50, 200) else ""),
-                       "chains": world, "hmc_mode": "sufficient-statistics", "burn_in": a.burn_in,
+                       "chains": world, "hmc_mode": hmc_mode,
+                       "hmc_mode_meaning": "0: O(N) sums folded into sufficient statistics once per Gibbs iteration (leapfrogs cost O(nnz Gram) on the host); 1: one O(N) device evaluation per leapfrog",
+                       "tree_path": tree_path, "burn_in": a.burn_in,
                        "n_leapfrog_timed": int(s1["sum_n_leapfrog"] - s0["sum_n_leapfrog"]),
                        "n_leapfrog_per_step": (s1["sum_n_leapfrog"] - s0["sum_n_leapfrog"]) / a.steps,
                        "mean_treedepth_timed": (s1["sum_treedepth"] - s0["sum_treedepth"]) / trans,
                        "divergent_timed": int(s1["divergent"] - s0["divergent"]),
                        "gradient_evals_timed": int(c1[0] - c0[0]), "tree_updates_timed": int(c1[1] - c0[1]),
+                       "fused_sum_evaluations": fused_stats[0], "fused_sum_fallbacks_to_doubles": fused_stats[1],
                        "sigma_last": [float(s[0]) for s in summ],
+                       "host_cores_per_rank": [int(s[4]) for s in summ],
                        "setup_seconds_per_rank": {"design (rank 0 generates, others load)": [float(s[1]) for s in summ],
                                                   "create (binning, upload, init)": [float(s[2]) for s in summ]}},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "avg_launch_us": dom_us, "algorithmic_bytes_per_launch": dom_bytes,
-                         "timing": "HIP events around every launch on the sampler's stream (adds ~2 us per launch; profiles/ has rocprofv3)",
-                         "separate_control_kernel_us": None if fused else prof["control_us"],
-                         "last_launch_of_sweep_us": prof["apply_us"],
-                         "sweep_wall_us": prof["sweep_wall_us"], "tree_update_wall_us": prof["sweep_wall_us"] / a.trees,
-                         "achieved_GBs_whole_sweep": dom_bytes * a.trees / (prof["sweep_wall_us"] * 1e-6) / 1e9,
-                         "measured_stream": probe,
-                         "frac_of_measured_update_stream": (achieved / probe["update_in_place_GBs"]) if probe else None},
         }
-        # second kernel group of the path: the O(N) sums one leapfrog costs when the gradient is evaluated on the device
-        # (hmc_mode 1, the reference's cost model).  The timed region above uses hmc_mode 0, where a leapfrog is O((K+q)^2)
-        # on the host from sufficient statistics gathered once per Gibbs iteration by the same kernel.
-        rec["roofline_hmc"] = {"bound": "hbm", "kernel": "k_stan_fused (direct)",
-                               "achieved": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                               "avg_eval_us": lf["kernels_us"], "avg_eval_us_with_result_fetch": lf["with_fetch_us"],
-                               "launches_per_eval": lf["launches"], "algorithmic_bytes_per_eval": lf["algorithmic_bytes"],
-                               "note": "N (8K + 12z + 20) bytes per leapfrog (SURVEY 8d B_lf); not in the timed region (hmc_mode 0)"}
+        if world > 1:
+            # scaling efficiency against the committed single-GPU line of this round (the driver computes its own from its N = 1 run)
+            try:
+                with open(os.path.join(ROOT, "profiles", "bench_n1_reference.json")) as f:
+                    ref1 = json.load(f)
+                if ref1.get("config", {}).get("workload") == rec["config"]["workload"]:
+                    rec["scaling_efficiency_vs_committed_n1"] = {"value": min(per_rank) / ref1["per_chain"], "n1_per_chain": ref1["per_chain"],
+                                                                 "definition": "slowest rank's per-chain rate / per-chain rate of profiles/bench_n1_reference.json"}
+            except (OSError, ValueError, KeyError):
+                pass
+        if dt1_max is not None:
+            rec["per_chain_hmc_mode1"] = {"value": a.steps / dt1_max, "unit": "Gibbs iterations/s/chain", "ms_per_step": 1e3 * dt1_max / a.steps,
+                                          "n_leapfrog_per_step": (m1["sum_n_leapfrog"] - m0["sum_n_leapfrog"]) / a.steps,
+                                          "note": "same chain, continued after the headline's timed region with hmc_mode 1: every leapfrog launches k_stan_fused over all N observations"}
+        if prof is not None:
+            # HBM traffic of the tree kernel: REPLAYED from the PMC passes committed under profiles/ (rocprofv3 cannot wrap this
+            # process from inside; collected on this command line by tools/profile_round.sh, see profiles/pmc_traffic.json)
+            traffic, traffic_note = None, None
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    pj = json.load(f)
+                ent = pj.get(str(n), {})
+                if ent.get("kernel", "").startswith(DOMINANT[tree_path]):
+                    traffic = ent.get("bytes_per_launch")
+                    traffic_note = "replayed from profiles/pmc_traffic.json (" + str(ent.get("kernel")) + "), not measured in this run"
+            except (OSError, ValueError):
+                pass
+            rf = sweep_roofline(prof, tree_path, n, a.trees, lag)
+            rf["traffic"], rf["traffic_note"] = traffic, traffic_note
+            rf["measured_stream"] = probe
+            rf["frac_of_measured_update_stream"] = (rf["achieved"] / probe["update_in_place_GBs"]) if probe else None
+            rec["roofline"] = rf
+            # second kernel group of the path: the O(N) sums one leapfrog costs when the gradient is evaluated on the device
+            rec["roofline_hmc"] = {"bound": "hbm", "kernel": "k_stan_fused (direct)",
+                                   "achieved": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                   "avg_eval_us": lf["kernels_us"], "avg_eval_us_with_result_fetch": lf["with_fetch_us"],
+                                   "launches_per_eval": lf["launches"], "algorithmic_bytes_per_eval": lf["algorithmic_bytes"],
+                                   "note": "N (8K + 12z + 20) bytes per leapfrog (SURVEY 8d B_lf); in the timed region of per_chain_hmc_mode1, not of the headline"}
         if target is not None:
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    target["traffic"] = json.load(f).get(str(a.target_n), {}).get("bytes_per_launch")
+                    ent = json.load(f).get(str(a.target_n), {})
+                target["traffic"] = ent.get("bytes_per_launch") if ent.get("kernel", "").startswith(target["kernel"]) else None
                 target["traffic_note"] = "replayed from profiles/pmc_traffic.json, not measured in this run"
             except (OSError, ValueError):
                 target["traffic"] = None
             if probe:
                 target["frac_of_measured_update_stream"] = target["achieved"] / probe["update_in_place_GBs"]
             rec["roofline_target_config"] = target
-        if world == 1 and not a.no_cpu_baseline:
+        if state_after_burn_in is not None:
             olib = oracle_lib()
-            cargs = case_from_design(d, a.p, a.trees, 0, 0, a.cpu_iters + 1)
-            v, secs = time_chain(olib, "orc_", cargs, 12345, 1, a.cpu_iters)
+            cargs = case_from_design(d, a.p, a.trees, 0, a.burn_in, total)
+            v, secs, lfc = cpu_baseline_from_state(olib, cargs, state_after_burn_in, a.cpu_iters)
             rec["cpu_baseline"] = {"value": v, "unit": "Gibbs iterations/s/chain", "cores": 1, "kind": "port",
-                                   "sample": f"same workload (n={n}, p={a.p}, ntree={a.trees}), {a.cpu_iters} Gibbs iterations from a cold chain "
-                                             f"(warm-up phase, 3-4 leapfrogs each), {secs:.1f} s of single-thread CPU time, host has {os.cpu_count()} cores",
-                                   "reference_R_package": "R is absent on this box (" + ("Rscript not found" if shutil.which("Rscript") is None else "Rscript present but the reference is not installed")
-                                                          + "): the CPU figure is the repo's C++ restatement (oracle/), not vdorie/stan4bart itself"}
-        if world == 1 and not a.no_extra_configs:
+                                   "sample": f"same workload (n={n}, p={a.p}, ntree={a.trees}), {a.cpu_iters} sampling-phase Gibbs iterations started from the GPU chain's state "
+                                             f"after the burn-in (adapted step size and metric; {lfc:.1f} leapfrogs per iteration, each O(N) as in the reference), "
+                                             f"{secs:.1f} s of single-thread CPU time, host has {os.cpu_count()} cores",
+                                   "reference_R_package": reference_r_leg(n, a.p, a.trees, a.cpu_iters)}
+        if world == 1 and not a.no_extra_configs and not a.emul:
             # BASELINE configs 1 and 2: small and quick, reported beside the headline
-            from stan4bart_amd import generate_friedman_data
+            from stan4bart_amd import GroupTerm, generate_friedman_data, make_sampler_args
             olib = oracle_lib()
             extra = {}
             d1 = generate_friedman_data(100, ranef=True, causal=True, p=10)
-            from stan4bart_amd import GroupTerm, make_sampler_args
             x1 = d1["x"]
             a1 = make_sampler_args(d1["y"], x1[:, [j for j in range(10) if j != 3]], X=np.column_stack([x1[:, 3], d1["z"]]),
                                    groups=[GroupTerm(d1["g1"], None, "g.1"), GroupTerm(d1["g2"], None, "g.2")], iter=400, warmup=200,

@@ -276,6 +276,12 @@ int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
 /* diagnostics of the one-launch O(N) sums of the Stan block (k_stan_fused): out = {evaluations, evaluations repeated in plain
  * doubles because the fixed-point range check failed (first evaluation, rescaled response, trajectory far outside the typical set)} */
 int S4B_FN(get_fused_stats)(s4b_sampler* s, int64_t out[2]);
+/* extension: how the Stan block evaluates the O(N) part of the log density (stan_control.hmc_mode): 0 = sufficient statistics
+ * gathered once per Gibbs iteration, 1 = one device evaluation per leapfrog (the reference's cost model).  A sampler created
+ * with mode 0 may be switched to 1 and back between runs (same posterior, same draws up to rounding); one created with mode 1
+ * has no Gram matrix and stays in mode 1. */
+int S4B_FN(set_hmc_mode)(s4b_sampler* s, int32_t mode);
+int S4B_FN(get_hmc_mode)(s4b_sampler* s, int32_t* mode);
 
 /* NUTS totals over all transitions since creation: {transitions, sum of treedepth__, sum of n_leapfrog__, divergent transitions}
  * (the per-draw values are columns 4-6 of the stan result; the totals let a caller that keeps no per-iteration output, keep_fits =

@@ -274,7 +274,7 @@ class Sampler:
             "get_leaf_assignment": [vp, i32, ip], "get_counters": [vp, C.POINTER(i64)], "get_nuts_stats": [vp, dp],
             "profile_sweep": [vp, i32, dp], "profile_leapfrog": [vp, i32, dp],
             "set_progress": [vp, PROGRESS, vp], "set_device_sharing": [vp, i32],
-            "set_tree_path": [vp, i32], "get_tree_path": [vp, ip], "get_lag_stats": [vp, dp], "get_fused_stats": [vp, C.POINTER(i64)],
+            "set_tree_path": [vp, i32], "get_tree_path": [vp, ip], "get_lag_stats": [vp, dp], "get_fused_stats": [vp, C.POINTER(i64)], "set_hmc_mode": [vp, i32], "get_hmc_mode": [vp, ip],
         }
         for name, argtypes in sig.items():
             fn = getattr(self._lib, self._pfx + name, None)
@@ -436,6 +436,17 @@ class Sampler:
             self._check(fn(self._h, _dp(out)))
         return {"sweeps": out[0], "launches_per_sweep": out[1], "repairs_per_sweep": out[2], "slow_passes": out[3],
                 "decisions_alone": out[4], "host_top_ups": out[5]}
+
+    def set_hmc_mode(self, mode: int):
+        self._check(self._f("set_hmc_mode")(self._h, int(mode)))
+
+    def get_hmc_mode(self) -> int:
+        fn = getattr(self._lib, self._pfx + "get_hmc_mode", None)
+        if fn is None:
+            return 1          # (the oracle evaluates the likelihood per leapfrog, like the reference)
+        out = np.zeros(1, dtype=np.int32)
+        self._check(fn(self._h, _ip(out)))
+        return int(out[0])
 
     def get_fused_stats(self):
         """(evaluations of the fused O(N) Stan sums, evaluations repeated in plain doubles after a failed range check)"""

@@ -207,7 +207,7 @@ class SamplerCore {
 
     // ---- Stan sampler: init + init_stepsize run against offset_ = 0 and the raw y (reference
     //      interruptable_sampler.hpp:150,175-176 happen before any BART fit exists)
-    if (hmcMode_ == 0) build_gram(sd);
+    if (hmcMode_ == 0) { build_gram(sd); haveGram_ = true; }
     dev_.stan_inputs(/*mode raw y*/ 0, false, cX_.data(), cZ_.data(), &s0_, nullptr);
     model_->lik = [this](const double* beta, const double* b, double* gX, double* gZ) { return likelihood(beta, b, gX, gZ); };
     NutsControl nc;
@@ -577,6 +577,13 @@ class SamplerCore {
 
   void set_trace(bool on) { live(); dev_.set_trace(on); }
   void set_device_sharing(int chains) { live(); dev_.set_device_sharing(chains); }
+  int hmc_mode() const { live(); return hmcMode_; }
+  void set_hmc_mode(int mode) {
+    live();
+    if (mode != 0 && mode != 1) throw std::invalid_argument("hmc_mode must be 0 (sufficient statistics) or 1 (one device evaluation per leapfrog)");
+    if (mode == 0 && !haveGram_) throw std::invalid_argument("this sampler was created with hmc_mode 1: it has no Gram matrix to evaluate from sufficient statistics");
+    hmcMode_ = mode;
+  }
   int64_t get_trace(int64_t cap, int32_t* out) { live(); return dev_.get_trace(cap, out); }
   void leaf_assignment(int t, int32_t* out) {
     live();
@@ -786,7 +793,7 @@ class SamplerCore {
   }
 
   Dev dev_;
-  size_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 256, thin_ = 1, K_ = 0, q_ = 0, hmcMode_ = 0;
+  size_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 256, thin_ = 1, K_ = 0, q_ = 0, hmcMode_ = 0; bool haveGram_ = false;
   int warmup_ = 0, verbose_ = 0, refresh_ = 0, offsetType_ = 0; s4b_progress_fn progress_ = nullptr; void* progressUser_ = nullptr; bool keepFits_ = true, hasUserOffset_ = false, binary_ = false;
   std::vector<double> userOffset_;
   s4b_callback_fn callback_ = nullptr; void* callbackUser_ = nullptr;

@@ -75,3 +75,41 @@ def test_split_rhat():
     assert np.all(np.abs(split_rhat(same) - 1.0) < 0.05)
     shifted = same + np.arange(4)[:, None, None] * 3.0
     assert np.all(split_rhat(shifted) > 1.5)
+
+
+def test_bench_two_ranks_over_gloo(emul_lib):
+    """The torchrun line the driver uses for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`), here
+    with world size 2 over gloo and the CPU emulation of the device layer (`--emul`, test only): rendezvous on 127.0.0.1, the design
+    generated once by rank 0 and shared through /dev/shm, per-rank core pinning, barrier + max-over-ranks timing, the end-of-run
+    all-gather, ONE JSON line from rank 0 with the contract's fields."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--burn-in", "4", "--num-obs", "300", "--p", "10", "--trees", "5",
+           "--emul", "--no-extra-configs", "--no-cpu-baseline", "--target-n", "0"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in rec, k
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak" and rec["config"]["chains"] == 2
+    assert len(rec["per_chain_by_rank"]) == 2 and abs(rec["value"] - 2 * rec["per_chain"]) < 1e-9
+    assert len(rec["config"]["sigma_last"]) == 2 and rec["config"]["sigma_last"][0] != rec["config"]["sigma_last"][1]   # two different chains
+    cores = rec["config"]["host_cores_per_rank"]
+    assert len(cores) == 2 and (os.cpu_count() < 2 or cores[0] <= os.cpu_count() // 2)      # disjoint core sets
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """one chain per GPU: WORLD_SIZE above the visible device count must fail loudly, not oversubscribe a device"""
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode != 0 and ("MI355X" in out.stderr or "GPU" in out.stderr)
