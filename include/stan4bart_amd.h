@@ -106,8 +106,10 @@ typedef struct {
 
 typedef int (*s4b_callback_fn)(void* user, const double* yhat_train, const double* yhat_test,
                                const double* stan_pars, int32_t num_pars);
-/* progress / cancellation hook of run(): called before iteration `iter` (1-based) of `num_iter` whenever iter is a multiple of
- * common_control.refresh (every iteration when refresh <= 0); a non-zero return stops the run (status 1, "interrupted ...").
+/* progress / cancellation hook of run(): called before iteration `iter` (1-based) of `num_iter` for iter = 1 and whenever iter is
+ * a multiple of common_control.refresh (every iteration when refresh <= 0); a non-zero return stops the run (status 1,
+ * "interrupted ...").  With a hook installed run() prints nothing itself: the hook's owner prints the reference's
+ * "starting warmup ..." and "iter k / n" lines (the R shim does, shim/init_shim.cpp).
  * Reference: "iter k / n" lines (src/init.cpp:752-754) and R_CheckUserInterrupt per transition (src/stan_sampler.hpp:44-48). */
 typedef int (*s4b_progress_fn)(void* user, int32_t iter, int32_t num_iter, int32_t is_warmup);
 
@@ -216,8 +218,12 @@ int S4B_FN(predict_bart)(s4b_sampler* s, const double* x_test, int64_t n_test, d
 /* the same with the reference's third argument: offset_test (n_test doubles, or NULL) is added to every draw's prediction */
 int S4B_FN(predict_bart_offset)(s4b_sampler* s, const double* x_test, int64_t n_test, const double* offset_test, double* out, int64_t* num_samples);
 
-/* Sampler state as one relocatable byte string: checkpoint / resume of a chain, and the hook of the teacher-forced parity
- * tests (state of one implementation injected into the other before every compared transition).  No reference routine
+/* The state of a chain BETWEEN TWO GIBBS ITERATIONS as one relocatable byte string: what the next iteration starts from.  It is
+ * the hook of the teacher-forced parity tests (state of one implementation injected into the other before every compared
+ * transition) and lets a chain continue in another sampler created from the same data; it is not an archive of a fit: the
+ * kept trees of keep_trees (export_bart_state carries those), the draws already returned, the tree-move trace and the
+ * counters of get_counters / get_nuts_stats stay with the sampler that produced them.  set_state validates the blob
+ * (dimensions, tree shapes, rule ranges, finite values, positive scales) before anything is changed.  No reference routine
  * does this: the reference can only re-run a chain from its seed (R/stan4bart_fit.R:33-60); what the blob holds is the
  * state the reference keeps between two iterations of src/init.cpp:752-917 —
  *   NUTS: current point, step size, dual-averaging scalars (stepsize_adaptation.hpp:10-65), window counters
@@ -253,7 +259,6 @@ int S4B_FN(set_trace)(s4b_sampler* s, int32_t enable);
 int S4B_FN(get_trace)(s4b_sampler* s, int64_t cap_records, int32_t* out, int64_t* num_records);
 /* DFS leaf rank of every training observation in tree t (n int32) */
 int S4B_FN(get_leaf_assignment)(s4b_sampler* s, int32_t tree, int32_t* out);
-/* counters: {log-density gradient evaluations, tree updates, device kernel launches} */
 /* Not a reference routine.  Hint that `chains` samplers share this sampler's device (R/stan4bart_fit.R:515-533 runs the chains of
  * one fit in parallel workers; here they can be host threads on one GPU).  The default tree update keeps every CU busy with one
  * register-heavy workgroup, which is fastest for a chain that has the device to itself; with three or more chains per device the
@@ -272,6 +277,7 @@ int S4B_FN(get_tree_path)(s4b_sampler* s, int32_t out[2]);
 /* lagged path only (zeros otherwise): out = {sweeps, launches used per sweep, repair launches per sweep (a speculated proposal image
  * did not hold), slow (one step at a time) passes, decisions without a statistics pass beside them, host top-ups} since creation */
 int S4B_FN(get_lag_stats)(s4b_sampler* s, double out[6]);
+/* counters: {log-density gradient evaluations, tree updates, device kernel launches} */
 int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
 /* diagnostics of the one-launch O(N) sums of the Stan block (k_stan_fused): out = {evaluations, evaluations repeated in plain
  * doubles because the fixed-point range check failed (first evaluation, rescaled response, trajectory far outside the typical set)} */

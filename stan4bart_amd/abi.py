@@ -249,6 +249,7 @@ class Sampler:
         self.num_pars, self.n, self.n_test, self.p, self.n_trees = (int(d) for d in dims)
         self.keep_fits = bool(a.keep_fits)
         self.callback_results: list = []
+        self._pending_exc = None
 
     # ------------------------------------------------------------------ plumbing
     def _bind(self):
@@ -298,7 +299,11 @@ class Sampler:
         tr = np.ctypeslib.as_array(yhat_train, shape=(self.n,)).copy()
         te = np.ctypeslib.as_array(yhat_test, shape=(self.n_test,)).copy() if self.n_test else None
         sp = np.ctypeslib.as_array(stan_pars, shape=(num_pars,)).copy()
-        self.callback_results.append(self._py_callback(tr, te, sp))
+        try:
+            self.callback_results.append(self._py_callback(tr, te, sp))
+        except BaseException as e:       # ctypes would swallow it: remember it, let the run finish its iteration, re-raise after
+            if self._pending_exc is None:
+                self._pending_exc = e
         return 0
 
     # ------------------------------------------------------------------ the .Call surface
@@ -313,7 +318,12 @@ class Sampler:
         res = Results(stan=_dp(stan), bart_sigma=_dp(sigma), bart_train=_dp(train),
                       bart_test=_dp(test) if self.n_test else None, bart_varcount=_ip(varcount))
         self.callback_results = []
-        self._check(self._f("run")(self._h, num_iter, int(is_warmup), results_type, C.byref(res)))
+        self._pending_exc = None
+        rc = self._f("run")(self._h, num_iter, int(is_warmup), results_type, C.byref(res))
+        if self._pending_exc is not None:           # an exception inside the per-iteration callback or the progress hook
+            e, self._pending_exc = self._pending_exc, None
+            raise e
+        self._check(rc)
         out = {}
         if results_type in (0, 2):
             out["stan"] = stan
@@ -402,7 +412,15 @@ class Sampler:
     def set_progress(self, fn):
         """``fn(iter, num_iter, is_warmup) -> bool`` (True cancels the run), or None."""
         self._progress_py = fn
-        self._progress_c = PROGRESS(lambda user, it, n, w: int(bool(fn(it, n, bool(w))))) if fn is not None else PROGRESS()
+
+        def hook(user, it, n, w):
+            try:
+                return int(bool(fn(it, n, bool(w))))
+            except BaseException as e:   # cancel the run (non-zero) and re-raise once s4b_run has returned
+                if self._pending_exc is None:
+                    self._pending_exc = e
+                return 1
+        self._progress_c = PROGRESS(hook) if fn is not None else PROGRESS()
         self._check(self._f("set_progress")(self._h, self._progress_c, None))
 
     def set_device_sharing(self, chains: int):

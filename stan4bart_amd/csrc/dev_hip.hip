@@ -1354,7 +1354,10 @@ __global__ __launch_bounds__(LB2) void k_latents2(BartArrays a, double* xacc) {
           next = p;
         }
         const long long sl = next - (p0 + lane) + lane - 2;      // slack of the next observation
-        S.T[i][lane] = bad ? (uint8_t)255 : (uint8_t)(sl > 254 ? 254 : sl);
+        // (a slack beyond the 8-bit table — one observation consuming more than ~250 positions — is treated like a candidate that ran
+        // out of generated positions: the chain stops before it; were it the first observation of a batch with the ring full, the
+        // batch makes no progress and the kernel raises S4B_ERR_INTERNAL below instead of continuing from a wrong position)
+        S.T[i][lane] = (bad || sl > 254) ? (uint8_t)255 : (uint8_t)sl;
         S.X[i][lane] = x;
       }
       __syncthreads();

@@ -555,6 +555,16 @@ class SamplerCore {
       if (!open.empty() || leaf != cnt[1]) throw std::invalid_argument("sampler state: malformed tree");
       h.hwm[(size_t)t] = cnt[0];
     }
+    // nothing non-finite reaches the device or the adaptation state (the blob may come from a file or another process)
+    {
+      auto finite = [](const double* x, size_t k) { for (size_t i = 0; i < k; ++i) if (!std::isfinite(x[i])) return false; return true; };
+      bool ok = finite(ns.q.data(), (size_t)D) && finite(ns.inv_metric.data(), (size_t)D) && finite(ns.wm.data(), (size_t)D) && finite(ns.wm2.data(), (size_t)D) &&
+                finite(sc6, 6) && finite(sc4, 4) && finite(off.data(), n_) && finite(fits.data(), n_) && (!binary_ || finite(lat.data(), n_)) &&
+                finite(h.mu.data(), h.mu.size());
+      for (int i = 0; i < 7 && ok; ++i) ok = !std::isnan(ns.last[i]);           // (energy__ / lp__ may legitimately be infinite)
+      for (int i = 0; i < D && ok; ++i) ok = ns.inv_metric[(size_t)i] > 0.0;
+      if (!ok || !(sc6[0] > 0.0)) throw std::invalid_argument("sampler state: non-finite value, non-positive step size or inverse metric");
+    }
     // ---- commit
     nuts_->set_state(ns);
     nuts_->current_row(row_.data());

@@ -80,25 +80,55 @@ def init_fit(y, Xc, groups, n, is_binary):
     Gaussian: least squares, sigma = sqrt(RSS / (n - rank)) (``sigma(lm)``).  Binomial: probit IRLS (``glm(family =
     binomial("probit"))``); the reference takes ``fitted(init_fit, type = "link")`` (R/stan4bart.R:172), and ``fitted()``
     ignores ``type`` for a glm, so what it hands to BART is the fitted mean Phi(eta) — reproduced here."""
-    from scipy import sparse
-    from scipy.special import ndtr
     y = np.asarray(y, dtype=np.float64)
     K = Xc.shape[1]
-    blocks = [sparse.csr_matrix(np.column_stack([np.ones(n), Xc]) if K else np.ones((n, 1)))]
+    D = np.column_stack([np.ones(n), Xc]) if K else np.ones((n, 1))          # dense part: intercept + fixed effects
+    facs = []                                                                # per grouping factor: 0-based dummy column of every row, -1 for the reference level
     for g in groups:
-        lev = np.asarray(g.levels, dtype=np.int64)
         if g.l < 2:
             continue
-        keep = lev >= 2
-        blocks.append(sparse.csr_matrix((np.ones(int(keep.sum())), (np.flatnonzero(keep), lev[keep] - 2)), shape=(n, g.l - 1)))
-    A = sparse.hstack(blocks, format="csr")
+        lev = np.asarray(g.levels, dtype=np.int64)
+        facs.append((np.where(lev >= 2, lev - 2, -1), g.l - 1))
+    m = D.shape[1] + sum(w for _, w in facs)
+
+    def apply(coef):                                                         # A @ coef without forming A
+        out = D @ coef[:D.shape[1]]
+        o = D.shape[1]
+        for col, w in facs:
+            c = np.concatenate([coef[o:o + w], [0.0]])                       # (index -1: the reference level adds nothing)
+            out = out + c[col]
+            o += w
+        return out
 
     def wls(wt, z):
-        Aw = A.multiply(wt[:, None]).tocsr() if wt is not None else A
-        G = (Aw.T @ A).toarray()
-        rhs = Aw.T @ z
+        # normal equations of [D | dummies] from per-level sums (numpy only): the Gram matrix is m x m, never n x m
+        Dw = D if wt is None else D * wt[:, None]
+        G = np.zeros((m, m)); rhs = np.zeros(m)
+        d = D.shape[1]
+        G[:d, :d] = Dw.T @ D
+        rhs[:d] = Dw.T @ z
+        ones = np.ones(n) if wt is None else wt
+        offs, o = [], d
+        for col, w in facs:
+            offs.append(o); o += w
+        for (col, w), o in zip(facs, offs):
+            in_ = col >= 0
+            for j in range(d):
+                G[j, o:o + w] = np.bincount(col[in_], weights=Dw[in_, j], minlength=w)
+            G[o:o + w, :d] = G[:d, o:o + w].T
+            rhs[o:o + w] = np.bincount(col[in_], weights=(ones * z)[in_], minlength=w)
+            for (col2, w2), o2 in zip(facs, offs):
+                both = in_ & (col2 >= 0)
+                blk = np.zeros((w, w2))
+                np.add.at(blk, (col[both], col2[both]), ones[both])
+                G[o:o + w, o2:o2 + w2] = blk
         coef, _, rank, _ = np.linalg.lstsq(G, rhs, rcond=1e-11)
         return coef, int(rank)
+
+    class _A:                                                                # (`A @ coef` below)
+        def __matmul__(self, coef):
+            return apply(coef)
+    A = _A()
 
     if not is_binary:
         coef, rank = wls(None, y)
@@ -106,9 +136,13 @@ def init_fit(y, Xc, groups, n, is_binary):
         sigma = float(np.sqrt(np.sum((y - fitted) ** 2) / max(1, n - rank)))
         return fitted, sigma
     # probit IRLS, glm.fit's scheme: mustart = (y + 0.5) / 2, eta = qnorm(mu), deviance convergence (epsilon = 1e-8, maxit 25)
-    from scipy.special import ndtri
+    try:
+        from scipy.special import ndtr                                       # (only the probit path needs scipy: the normal cdf)
+    except ImportError as e:                                                 # pragma: no cover
+        raise ImportError("family = 'binomial' needs scipy (scipy.special.ndtr) for the probit starting values") from e
+    from .rcompat import qnorm
     mu = (y + 0.5) / 2.0
-    eta = ndtri(mu)
+    eta = qnorm(mu)
     dev_old = np.inf
     for _ in range(25):
         dmu = np.exp(-0.5 * eta * eta) / np.sqrt(2.0 * np.pi)

@@ -381,7 +381,7 @@ def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=N
     results, samplers = [None] * chains, [None] * chains
     args_box = [None]
 
-    def one_chain(c, chain_rng):
+    def one_chain(c, chain_rng, sharing=1):
         args = make_sampler_args(y, x_bart, X=X, groups=groups, x_test=x_bart_test, family=family, iter=iter, warmup=warmup,
                                  offset=offset, offset_type=offset_type, keep_fits=True, callback=cb, **kw)
         args_box[0] = args
@@ -389,8 +389,8 @@ def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=N
         s = make_sampler(args, chain_rng.state)
         r = {}
         try:
-            if cores > 1 and chains > 1 and hasattr(s, "set_device_sharing"):
-                s.set_device_sharing(min(cores, chains))      # host threads sharing one GPU
+            if sharing > 1 and hasattr(s, "set_device_sharing"):
+                s.set_device_sharing(sharing)                 # host threads that share the GPU while this chain runs (its batch)
             names_box[:] = [s.stan_par_names()]
             if warmup > 0:
                 r["warmup"] = s.run(warmup, True, 0)
@@ -422,15 +422,15 @@ def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=N
         seeds = chain_seeds(int(rng.sample_int(INT_MAX, 1)[0]) if seed is None else seed, chains)
         errors = []
 
-        def guarded(c):
+        def guarded(c, sharing):
             try:
-                one_chain(c, RRng(int(seeds[c])))
+                one_chain(c, RRng(int(seeds[c])), sharing)
             except Exception as e:   # surfaced after the join
                 errors.append(e)
         pending = list(range(chains))
         while pending:
             batch, pending = pending[:cores], pending[cores:]
-            th = [threading.Thread(target=guarded, args=(c,)) for c in batch]
+            th = [threading.Thread(target=guarded, args=(c, len(batch))) for c in batch]
             [t.start() for t in th]
             [t.join() for t in th]
         if errors:

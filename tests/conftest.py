@@ -258,6 +258,8 @@ def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True, sharing
             traces.append(s.get_trace())
             out["trace"] = np.concatenate(traces)
         out["trees"] = s.get_trees()
+        if getattr(args, "keep_trees", False) and hasattr(s, "get_kept_trees"):
+            out["kept_trees"] = s.get_kept_trees()
         out["rng"] = s.get_r_rng_state()
         out["leaf0"] = s.get_leaf_assignment(0)
         out["names"] = s.stan_par_names()

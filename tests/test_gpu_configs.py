@@ -96,5 +96,18 @@ def test_config5_full_size_properties(hip_lib):
     s2.disengage_adaptation()
     r2 = s2.run(2, False)
     assert np.array_equal(rng_state, s2.get_r_rng_state())
-    s2.free()
     assert np.array_equal(r2["bart"]["train"], r["bart"]["train"]) and np.array_equal(r2["stan"], r["stan"])
+    # the two gradient modes at the largest N: hmc_mode 0 evaluates s0 - 2 theta'c + theta'G theta from sums gathered once per
+    # iteration (cancellation grows with N), hmc_mode 1 sums the N residuals at every leapfrog.  Same state, one iteration each.
+    st = s2.get_state()
+    s2.set_trace(True)
+    a0 = s2.run(1, False)
+    t0 = s2.get_trace()
+    s2.set_state(st)
+    s2.set_hmc_mode(1)
+    a1 = s2.run(1, False)
+    t1 = s2.get_trace()
+    s2.free()
+    assert np.array_equal(a0["stan"][3:6], a1["stan"][3:6]) and np.array_equal(t0, t1)
+    np.testing.assert_allclose(a0["stan"], a1["stan"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(a0["bart"]["train"], a1["bart"]["train"], rtol=1e-6, atol=1e-9)

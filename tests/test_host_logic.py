@@ -286,7 +286,24 @@ def test_interface_details_of_the_call_layer(emul_lib, capfd):
     with pytest.raises(RuntimeError, match="interrupted"):
         s.run(5, False)
     assert seen[-1] == (3, 5, False)
+    # an exception inside the hook cancels the run and comes back to the caller (ctypes alone would swallow it)
+    def boom(it, n, w):
+        if it >= 2:
+            raise KeyError("from the progress hook")
+        return False
+    s.set_progress(boom)
+    with pytest.raises(KeyError, match="from the progress hook"):
+        s.run(5, False)
     s.set_progress(None)
+    s.run(1, False)              # the sampler is still usable
+    s.free()
+    # ... and so does an exception inside the per-iteration callback
+    import copy
+    a2 = copy.copy(args)
+    a2.callback = lambda tr, te, sp: (_ for _ in ()).throw(ValueError("from the callback"))
+    s = make_sampler(emul_lib, "emu_", a2)
+    with pytest.raises(ValueError, match="from the callback"):
+        s.run(2, True)
     s.free()
     # verbose / refresh without a hook: the reference's lines
     args.verbose, args.refresh = 2, 2

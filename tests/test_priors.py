@@ -124,6 +124,28 @@ def test_product_host_model_matches_oracle(oracle_lib, emul_lib, prior):
     assert names_ok
 
 
+def test_hs_hand_off_uses_the_coefficients_not_the_local_scales(emul_lib):
+    """The reference's get_parametric_mean skips `2 + K` slots for hs priors (src/stan_files/continuous.hpp:3673) where
+    write_array emits `hs + hs K + 1` (global, local, caux; get_aux skips those correctly, :3640-3646): under hs / hs_plus it hands
+    BART X times the wrong slice of the sample row.  This path deliberately FIXES that (beta_pos()): the parametric mean is
+    X beta + Z b with the row's own `beta.*` and `b.*` entries."""
+    from stan4bart_amd import RRng
+    from stan4bart_amd.abi import Sampler
+    for dist in ("hs", "hs_plus"):
+        args = _args({"dist": dist})
+        s = Sampler(emul_lib, "emu_", args, RRng(3).state)
+        row = s.run(3, True)["stan"][:, -1]
+        names, pm = s.stan_par_names(), s.get_parametric_mean()
+        s.free()
+        beta = np.array([row[names.index(f"beta.{k + 1}")] for k in range(np.asarray(args.X).shape[1])])
+        b = np.array([row[i] for i, nm in enumerate(names) if nm.startswith("b.")])
+        eta = np.asarray(args.X) @ beta
+        u, v, w = np.asarray(args.u), np.asarray(args.v), np.asarray(args.w)
+        for i in range(len(eta)):
+            eta[i] += np.dot(w[u[i]:u[i + 1]], b[v[u[i]:u[i + 1]]])
+        np.testing.assert_allclose(pm, eta, rtol=1e-12, atol=1e-12)
+
+
 def test_hs_rejected_for_binary(emul_lib):
     from stan4bart_amd import GroupTerm, RRng, generate_friedman_data, make_sampler_args
     from stan4bart_amd.abi import Sampler

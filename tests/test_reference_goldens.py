@@ -44,6 +44,13 @@ def _compare(g, d, out):
             np.testing.assert_allclose(ours[nm], stan[i], rtol=1e-6, atol=1e-9, err_msg=nm)
             matched += 1
     assert matched >= 20
+    # the kept trees, flattened as extract(fit, "trees") does (reference src/init.cpp:514-671: 1-based sample / tree / var, -1 = leaf)
+    kt, gt = out["kept_trees"], g["trees"]
+    np.testing.assert_array_equal(kt["sample"] + 1, gt["sample"])
+    np.testing.assert_array_equal(kt["tree"] + 1, gt["tree"])
+    np.testing.assert_array_equal(kt["n"], gt["n"])
+    np.testing.assert_array_equal(np.where(kt["var"] >= 0, kt["var"] + 1, -1), gt["var"])
+    np.testing.assert_allclose(kt["value"], gt["value"], rtol=1e-6, atol=1e-9)
 
 
 @needs_golden
@@ -59,3 +66,20 @@ def test_hip_matches_reference_goldens(hip_lib):
     g = _load()
     d, out = _chain(hip_lib, "s4b_")
     _compare(g, d, out)
+
+
+def test_golden_comparison_runs_on_a_self_made_file(oracle_lib, emul_lib):
+    """No reference file exists here; so that the day one appears the two tests above run unmodified, the comparison itself is
+    exercised on a dictionary in the file's layout (what tools/make_goldens.R writes) made from the oracle's own chain, against
+    the product's host logic over the emulation."""
+    d, o = _chain(oracle_lib, "orc_")
+    kt = o["kept_trees"]
+    g = {"data": {"x": d["x"].ravel(order="F").tolist(), "x_dim": list(d["x"].shape), "y": d["y"].tolist(), "g1": d["g1"].tolist()},
+         "bart_train": o["sample"]["bart"]["train"].ravel(order="F").tolist(), "bart_train_dim": list(o["sample"]["bart"]["train"].shape),
+         "varcount": o["sample"]["bart"]["varcount"].ravel(order="F").tolist(), "sigma": o["sample"]["bart"]["sigma"].tolist(),
+         "stan": o["sample"]["stan"].ravel(order="F").tolist(), "stan_dim": list(o["sample"]["stan"].shape), "par_names": o["names"],
+         "trees": {"sample": (kt["sample"] + 1).tolist(), "tree": (kt["tree"] + 1).tolist(), "n": kt["n"].tolist(),
+                   "var": np.where(kt["var"] >= 0, kt["var"] + 1, -1).tolist(), "value": kt["value"].tolist()}}
+    g = json.loads(json.dumps(g))
+    _, e = _chain(emul_lib, "emu_")
+    _compare(g, d, e)
