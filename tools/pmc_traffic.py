@@ -16,11 +16,20 @@ def avg(db, counter):
     sel = "counter_name" if "counter_name" in cols else "pmc_name"
     val = "value" if "value" in cols else "counter_value"
     best = (0, None, None)
-    for pat, label in (("%k_step<%", "k_step"), ("%k_tree<true%", "k_tree<true>")):
+    for pat, label in (("%k_step<%", "k_step"), ("%k_tree<true%", "k_tree<true>"), ("%k_lag(%", "k_lag")):
         row = c.execute(f"select count(*), avg({val}) from pmc_events where {kcol} like ? and {sel} = ?", (pat, counter)).fetchone()
         if row[0] and row[0] > best[0]:
             best = (row[0], row[1], label)
     return best
+
+
+def one(db, counter, pat):
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(pmc_events)")]
+    kcol = "kernel_name" if "kernel_name" in cols else "name"
+    sel = "counter_name" if "counter_name" in cols else "pmc_name"
+    val = "value" if "value" in cols else "counter_value"
+    return c.execute(f"select count(*), avg({val}) from pmc_events where {kcol} like ? and {sel} = ?", (pat, counter)).fetchone()
 
 
 if __name__ == "__main__":
@@ -30,4 +39,14 @@ if __name__ == "__main__":
     out = {"n": n, "kernel": kernel, "launches": [nf, nw], "FETCH_SIZE_kb": f, "WRITE_SIZE_kb": w,
            "bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0, "algorithmic_bytes": 22.0 * n,
            "correction": "2 x FETCH_SIZE (gfx950: 128-B requests tallied at 64 B) + WRITE_SIZE, KiB -> bytes"}
+    # the other kernels of the path, same correction: the per-leapfrog sums (direct) and the once-per-iteration sums of the Stan
+    # block, the control kernel of the two-kernel path, the lagged launch
+    others = {}
+    for pat, label in (("%k_stan_fused<%true>%", "k_stan_fused<direct>"), ("%k_stan_fused<%false>%", "k_stan_fused<per-iteration>"), ("%k_control%", "k_control"),
+                       ("%k_lag(%", "k_lag"), ("%k_stan_forward%", "k_stan_forward")):
+        cf, vf = one(sys.argv[1], "FETCH_SIZE", pat)
+        cw, vw = one(sys.argv[2], "WRITE_SIZE", pat)
+        if cf and cw:
+            others[label] = {"launches": [cf, cw], "FETCH_SIZE_kb": vf, "WRITE_SIZE_kb": vw, "bytes_per_launch": 2.0 * vf * 1024.0 + vw * 1024.0}
+    out["other_kernels"] = others
     print(json.dumps(out))
