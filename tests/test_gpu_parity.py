@@ -202,6 +202,17 @@ def test_probit_matches_oracle(oracle_lib, hip_lib, kw):
     assert np.all(a["sample"]["bart"]["sigma"] == 1.0) and "aux.1" not in b["names"]
 
 
+@pytest.mark.parametrize("path", ["lagged", "two-kernel"])
+def test_probit_and_thinning_on_the_other_tree_paths(oracle_lib, hip_lib, path):
+    """binary response (latents drawn between sweeps from the same generator the sweep leaves in slot 0) and skip = (2, 1): two BART
+    sweeps per Gibbs iteration, on the lagged and on the two-kernel tree update"""
+    for args in (_binary_case(n=747, T=20, n_test=11), friedman_case(n=1200, T=9, skip=(2, 1), warmup=5, iter=10)[0]):
+        a = run_chain(oracle_lib, "orc_", args)
+        b = run_chain(hip_lib, "s4b_", args, tree_path=path)
+        assert b["tree_path"][1] == path
+        assert_chain_parity(a, b)
+
+
 def test_trees_with_more_than_128_node_slots(oracle_lib, hip_lib):
     """regression: the LDS records of k_tree are carved by size; a tree that uses > 128 node slots exercises the
     upper half of every table (control code takes the global-memory path there: > 64 slots)."""
