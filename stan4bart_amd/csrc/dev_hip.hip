@@ -1957,7 +1957,7 @@ class DevHip {
       a.partF = zalloc<double>((size_t)2 * 3 * a.binCap * a.gridF);
       // lagged path (dev_lag.inc): the same grid; one control workgroup + pass workgroups that never wait for a decision
       ldsLag_ = lag_lds_bytes(nc_);
-      lagOk_ = d.weights == nullptr && ldsLag_ + 40 * 1024 <= 160 * 1024 && a.gridF <= 256;
+      lagOk_ = d.weights == nullptr && ldsLag_ + 40 * 1024 <= 160 * 1024 && a.gridF <= F_GRID_MAX;
       if (lagOk_) {
         lag_.desc = zalloc<int32_t>((size_t)2 * LD_WORDS); lag_.apply = zalloc<LagApply>(2); lag_.gtab = zalloc<uint32_t>((size_t)2 * LAG_XCD * LAG_TAB * LAG_PAD);
         lag_.cells = zalloc<uint8_t>((size_t)3 * a.npad); lag_.stat = zalloc<int32_t>(LS_WORDS);
