@@ -2003,7 +2003,8 @@ class DevHip {
       if (const char* f = getenv("S4B_STAN_FUSED")) stanFused_ = stanFused_ && atoi(f) != 0;
       if (stanFused_) {
         fusedAcc_ = zalloc<unsigned long long>((size_t)2 * S_XCD * fused_words((int)M)); fusedBad_ = zalloc<int32_t>(2);
-        HIP_OK(hipHostMalloc(&pinnedAcc_, sizeof(unsigned long long) * (fused_words((int)M) + 8), hipHostMallocDefault));
+        // (coherent: the device's stores reach host memory when they are released, not at the end of the kernel — the host polls this buffer)
+        HIP_OK(hipHostMalloc(&pinnedAcc_, sizeof(unsigned long long) * (fused_words((int)M) + 8), hipHostMallocCoherent | hipHostMallocMapped));
         std::memset(pinnedAcc_, 0, sizeof(unsigned long long) * (fused_words((int)M) + 8));
         fusedTicket_ = zalloc<uint32_t>(4);
         // every row of Z with the same number of non-zeros (the usual case: one per grouping-term coefficient): no row pointers needed
