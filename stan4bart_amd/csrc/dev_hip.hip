@@ -1552,14 +1552,15 @@ __global__ __launch_bounds__(BLOCK) void k_stan_finalize(BartArrays a, StanArray
 // Order-independent, hence deterministic, accumulation: every partial sum is multiplied by a power of two chosen per group of
 // sums (|e|^2; X'e; Z'e — `scale`, from the magnitudes the previous evaluation saw), split into two 64-bit fixed-point limbs
 // (2^-20 and 2^-56 units: together finer than the rounding of the double it came from) and added with INTEGER atomics — LDS
-// histogram for Z'e, per-XCD global accumulators for everything — so there are no per-workgroup partial arrays, no second kernel
-// and no finalize pass; the host adds the eight per-XCD copies (exact integer adds) after one small device-to-host copy.
+// histogram per wave for Z'e, 32 copies of the global accumulators for everything (workgroup b adds into copy b mod 32) — so there
+// are no per-workgroup partial arrays and no finalize pass over them; k_stan_forward adds the copies (exact integer adds) and hands
+// the result to the host.
 // Range: beside the sums, every group accumulates the sum of the ABSOLUTE values of what went into it (coarse units of 2^10, rounded
-// up).  While that total stays below 2^42 no partial sum anywhere (LDS slot, per-XCD copy, host total) can leave the 64-bit limb;
+// up).  While that total stays below 2^42 no partial sum anywhere (LDS slot, global copy, folded total) can leave the 64-bit limb;
 // the host checks it and, when it does not hold (first evaluation, a response rescaled by orders of magnitude, a trajectory far
 // outside the typical set), evaluates the same sums in plain doubles (reduce_pipeline) and re-centres the scales.
 constexpr int SBLOCK = 256;
-constexpr int S_XCD = 32;            // copies of the global accumulators (workgroup b adds into copy b % 32: fewer atomics meet on one address)
+constexpr int S_COPIES = 32;            // copies of the global accumulators (workgroup b adds into copy b % 32: fewer atomics meet on one address)
 constexpr int S_QMAX = 4096;          // Z'e histogram in LDS: 16 B per column (+ 8 B for b)
 constexpr double S_FX_LIMIT = 4398046511104.0;   // 2^42
 constexpr int S_PAR_INLINE = 64;
@@ -1572,14 +1573,13 @@ __device__ __forceinline__ FxLimbs fx_split(double v) {
 }
 __host__ __device__ static inline size_t fused_words(int M) { return (size_t)2 * M + 6; }   // limbs of the M sums + three magnitude words + three exponent words
 struct StanFusedArgs {
-  unsigned long long* acc;    // [2][S_XCD][fused_words]: accumulators of this launch (parity) and of the next one (cleared here)
+  unsigned long long* acc;    // [2][S_COPIES][fused_words]: accumulators of this launch (parity) and of the next one (cleared here)
   int32_t* bad;               // [2]: something non-finite or beyond 2^42 after scaling went into a sum
   int32_t parity, mode, wantTrain;
   double scale[3];            // powers of two: |e|^2, X'e, Z'e
-  // result hand-off without a copy command: the workgroup that finishes last folds nothing, it just forwards the per-XCD copies,
-  // the magnitude words and the flag to host memory the device can write (hostOut, same layout as one parity of acc + 1 word)
-  // and then publishes `seq` in hostOut[S_XCD * fused_words + 1]; the host polls that word
-  unsigned long long* hostOut; uint32_t* ticket; uint32_t seq; int32_t zFixed;   // zFixed: every row of Z has exactly this many non-zeros (u[i] = zFixed i), -1: general CSR
+  // result hand-off without a copy command: k_stan_forward folds the copies into host memory the device can write
+  // (hostOut: [fused_words] sums, [1] flag) and then publishes `seq` in hostOut[fused_words + 1]; the host polls that word
+  unsigned long long* hostOut; uint32_t seq; int32_t zFixed;   // zFixed: every row of Z has exactly this many non-zeros (u[i] = zFixed i), -1: general CSR
   // DIRECT: beta, b travel in the kernel arguments when they are few (no host-to-device copy, no wait for the staging buffer)
   int32_t parInline, pad; double par[S_PAR_INLINE];
 };
@@ -1599,8 +1599,8 @@ __global__ __launch_bounds__(SBLOCK) void k_stan_fused(BartArrays a, StanArrays 
   for (int j = threadIdx.x; j < 2 * q * nCopy; j += SBLOCK) zhAll[j] = 0ull;
   if (DIRECT) for (int j = threadIdx.x; j < K + q; j += SBLOCK) par[j] = f.parInline ? f.par[j < S_PAR_INLINE ? j : 0] : s.params[j];
   {   // clear the accumulators the NEXT evaluation uses (the host has consumed them: it waits for every evaluation)
-    unsigned long long* other = f.acc + (size_t)(1 - f.parity) * S_XCD * W;
-    const size_t tot = (size_t)S_XCD * W;
+    unsigned long long* other = f.acc + (size_t)(1 - f.parity) * S_COPIES * W;
+    const size_t tot = (size_t)S_COPIES * W;
     for (size_t j = (size_t)blockIdx.x * SBLOCK + threadIdx.x; j < tot; j += (size_t)gridDim.x * SBLOCK) other[j] = 0ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) f.bad[1 - f.parity] = 0;
   }
@@ -1697,7 +1697,7 @@ __global__ __launch_bounds__(SBLOCK) void k_stan_fused(BartArrays a, StanArrays 
   { const double v = wave_sum(mX); if (lane == 0) red[wv][KMAX + 1] = v; }
   { const double v = wave_sum(mZ); if (lane == 0) red[wv][KMAX + 2] = v; }
   __syncthreads();
-  unsigned long long* mine = f.acc + ((size_t)f.parity * S_XCD + (blockIdx.x % S_XCD)) * W;
+  unsigned long long* mine = f.acc + ((size_t)f.parity * S_COPIES + (blockIdx.x % S_COPIES)) * W;
   if ((int)threadIdx.x <= K) {
     const int k = threadIdx.x;
     const double v = (((red[0][k] + red[1][k]) + red[2][k]) + red[3][k]) * (k == 0 ? sS : sX);
@@ -1730,12 +1730,12 @@ __global__ __launch_bounds__(SBLOCK) void k_stan_fused(BartArrays a, StanArrays 
 // k_stan_fused on the same stream: no copy command, no stream synchronisation).  hostOut: [fused_words] sums, [1] flag, [1] seq
 __global__ __launch_bounds__(SBLOCK) void k_stan_forward(StanFusedArgs f, int M) {
   const size_t W = fused_words(M);
-  const unsigned long long* src = f.acc + (size_t)f.parity * S_XCD * W;
+  const unsigned long long* src = f.acc + (size_t)f.parity * S_COPIES * W;
   for (size_t j = threadIdx.x; j < W; j += SBLOCK) {
     unsigned long long v = 0ull;
     const bool isMax = j >= 2 * (size_t)M + 3;
 #pragma unroll 8
-    for (int x = 0; x < S_XCD; ++x) { const unsigned long long t = src[(size_t)x * W + j]; v = isMax ? (t > v ? t : v) : v + t; }
+    for (int x = 0; x < S_COPIES; ++x) { const unsigned long long t = src[(size_t)x * W + j]; v = isMax ? (t > v ? t : v) : v + t; }
     f.hostOut[j] = v;
   }
   if (threadIdx.x == 0) f.hostOut[W] = (unsigned long long)f.bad[f.parity];
@@ -1959,7 +1959,7 @@ class DevHip {
       ldsLag_ = lag_lds_bytes(nc_);
       lagOk_ = d.weights == nullptr && ldsLag_ + 40 * 1024 <= 160 * 1024 && a.gridF <= F_GRID_MAX;
       if (lagOk_) {
-        lag_.desc = zalloc<int32_t>((size_t)2 * LD_WORDS); lag_.apply = zalloc<LagApply>(2); lag_.gtab = zalloc<uint32_t>((size_t)2 * LAG_XCD * LAG_TAB * LAG_PAD);
+        lag_.desc = zalloc<int32_t>((size_t)2 * LD_WORDS); lag_.apply = zalloc<LagApply>(2); lag_.gtab = zalloc<uint32_t>((size_t)2 * LAG_COPIES * LAG_TAB * LAG_PAD);
         lag_.cells = zalloc<uint8_t>((size_t)3 * a.npad); lag_.stat = zalloc<int32_t>(LS_WORDS);
         HIP_OK(hipHostMalloc(&pinnedLag_, sizeof(int32_t) * 16, hipHostMallocDefault));
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLag_));
@@ -1996,17 +1996,16 @@ class DevHip {
     s.out = zalloc<double>((size_t)(1 + K_ + q_));
     s.mmPart = zalloc<double>((size_t)2 * a.grid);
     HIP_OK(hipHostMalloc(&pinned_, sizeof(double) * (size_t)(2 * (1 + K_ + q_) + 64), hipHostMallocDefault));
-    {   // fused Stan sums: fixed-point accumulators (two parities, one copy per XCD), LDS histogram of Z'e
+    {   // fused Stan sums: fixed-point accumulators (two parities, 32 copies), LDS histograms of Z'e
       const size_t M = (size_t)(1 + K_ + q_);
       fusedLds_ = (size_t)q_ * 16 * ((size_t)q_ * 16 * (SBLOCK / 64) <= 32768 ? SBLOCK / 64 : 1) + (size_t)(K_ + q_) * 8 + 16;
       stanFused_ = K_ <= 16 && q_ <= S_QMAX;
       if (const char* f = getenv("S4B_STAN_FUSED")) stanFused_ = stanFused_ && atoi(f) != 0;
       if (stanFused_) {
-        fusedAcc_ = zalloc<unsigned long long>((size_t)2 * S_XCD * fused_words((int)M)); fusedBad_ = zalloc<int32_t>(2);
+        fusedAcc_ = zalloc<unsigned long long>((size_t)2 * S_COPIES * fused_words((int)M)); fusedBad_ = zalloc<int32_t>(2);
         // (coherent: the device's stores reach host memory when they are released, not at the end of the kernel — the host polls this buffer)
         HIP_OK(hipHostMalloc(&pinnedAcc_, sizeof(unsigned long long) * (fused_words((int)M) + 8), hipHostMallocCoherent | hipHostMallocMapped));
         std::memset(pinnedAcc_, 0, sizeof(unsigned long long) * (fused_words((int)M) + 8));
-        fusedTicket_ = zalloc<uint32_t>(4);
         // every row of Z with the same number of non-zeros (the usual case: one per grouping-term coefficient): no row pointers needed
         zFixed_ = -1;
         if (q_ && d.u && n_ > 0) {
@@ -2541,7 +2540,7 @@ class DevHip {
   void launch_stan_fused(int mode, int wantTrain, bool direct) {
     StanFusedArgs f; f.acc = fusedAcc_; f.bad = fusedBad_; f.parity = fusedParity_; f.mode = mode; f.wantTrain = wantTrain;
     for (int g = 0; g < 3; ++g) f.scale[g] = std::ldexp(1.0, fxExp_[g]);
-    f.hostOut = pinnedAcc_; f.ticket = fusedTicket_; f.seq = ++fusedSeq_; f.zFixed = zFixed_;
+    f.hostOut = pinnedAcc_; f.seq = ++fusedSeq_; f.zFixed = zFixed_;
     f.parInline = (direct && K_ + q_ <= S_PAR_INLINE && inlineBeta_) ? 1 : 0; f.pad = 0;
     if (f.parInline) { for (int k = 0; k < K_; ++k) f.par[k] = inlineBeta_[k]; for (int j = 0; j < q_; ++j) f.par[K_ + j] = inlineB_[j]; }
     const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, (n_ + SBLOCK - 1) / SBLOCK));
@@ -2739,7 +2738,7 @@ class DevHip {
   double* pinned_ = nullptr; double* testOut_ = nullptr; double* latX_ = nullptr;
   unsigned long long* fusedAcc_ = nullptr; int32_t* fusedBad_ = nullptr; unsigned long long* pinnedAcc_ = nullptr;
   size_t fusedLds_ = 0; int fusedParity_ = 0; bool stanFused_ = false;
-  uint32_t* fusedTicket_ = nullptr; uint32_t fusedSeq_ = 0; int zFixed_ = -1; const double* inlineBeta_ = nullptr; const double* inlineB_ = nullptr;
+  uint32_t fusedSeq_ = 0; int zFixed_ = -1; const double* inlineBeta_ = nullptr; const double* inlineB_ = nullptr;
   int fxExp_[3] = {0, 0, 0}; int64_t fusedEvals_ = 0, fusedFallbacks_ = 0, fxLastBad_ = -2; bool fxTinyFail_ = false;
   int64_t launches_ = 0;
 };
