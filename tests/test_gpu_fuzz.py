@@ -1,0 +1,90 @@
+"""Seeded random configurations: the HIP path against the oracle on shapes nobody wrote down by hand.
+
+Every case draws its own problem (observations 4 … 40000, 1 … 69 predictors of mixed kinds — continuous, binary, few-level,
+duplicated —, 1 … 20 trees, cut counts 1 … 100, shallow and deep tree priors, weights, probit, grouping terms, test rows,
+thinning) from `numpy.random.default_rng(seed)` and runs it on each of the three tree-update paths.  Same bar as
+test_gpu_parity.py: trace / trees / generator state bit-exact, floating-point state to 1e-6.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_chain_parity, run_chain
+
+pytestmark = pytest.mark.gpu
+PATHS = ["fused", "two-kernel", "lagged"]
+
+
+def random_case(seed):
+    from stan4bart_amd import GroupTerm, make_sampler_args
+    g = np.random.default_rng(1000 + seed)
+    n = int(g.choice([g.integers(4, 40), g.integers(40, 400), g.integers(400, 3001), g.integers(3001, 40001)], p=[0.3, 0.3, 0.28, 0.12]))
+    p = int(g.integers(1, 9)) if g.random() < 0.85 else int(g.integers(9, 70))
+    cols = []
+    for j in range(p):
+        kind = g.integers(0, 5)
+        if kind == 0:
+            cols.append((g.random(n) < 0.3).astype(np.float64))                    # binary
+        elif kind == 1:
+            cols.append(g.integers(0, int(g.integers(2, 6)), size=n).astype(np.float64))   # few levels
+        elif kind == 2 and cols:
+            cols.append(cols[int(g.integers(0, len(cols)))].copy())               # a duplicated predictor
+        else:
+            cols.append(g.normal(size=n) if g.random() < 0.5 else g.random(n))
+    xb = np.column_stack(cols)
+    if np.all(xb.max(axis=0) == xb.min(axis=0)):
+        xb[:, 0] = g.random(n)                                                     # (at least one predictor that can be split on)
+    binary = bool(g.random() < 0.25)
+    ranef = bool(g.random() < 0.5) and n >= 12
+    x4 = g.random(n)
+    groups = []
+    f = 3.0 * np.sin(2.0 * xb[:, 0]) + (xb[:, -1] > np.median(xb[:, -1])) * 2.0 + 1.5 * x4
+    if ranef:
+        g1 = g.integers(1, int(g.integers(2, 7)) + 1, size=n)
+        slopes = bool(g.random() < 0.4) and not binary
+        groups.append(GroupTerm(g1, x4 if slopes else None, "g.1"))
+        f = f + g.normal(size=int(g1.max()))[g1 - 1]
+        if g.random() < 0.4:
+            g2 = g.integers(1, 4, size=n)
+            groups.append(GroupTerm(g2, None, "g.2"))
+    yc = f + g.normal(size=n) * g.choice([0.1, 1.0, 3.0])
+    y = (yc > np.median(yc)).astype(np.float64) if binary else yc * g.choice([1.0, 1e-3, 250.0])
+    if binary and (y.min() == y.max()):
+        y[0] = 1.0 - y[0]
+    weights = None if (binary or g.random() < 0.7) else g.random(n) + 0.25
+    deep = g.random() < 0.3
+    bart_args = {"n.trees": int(g.integers(1, 21)), "n.cuts": int(g.choice([1, 2, 5, 100])), "k": float(g.choice([0.5, 2.0, 4.0]))}
+    if deep:
+        bart_args.update(base=0.99, power=0.5)
+    warmup = int(g.integers(2, 12))
+    it = warmup + int(g.integers(4, 40 if deep else 25))
+    n_test = int(g.integers(0, 3)) * int(g.integers(1, min(n, 20)))
+    joint = bool(g.random() < 0.35)
+    skip = (int(g.integers(1, 3)), int(g.integers(1, 3))) if joint and g.random() < 0.3 else 1
+    if joint:
+        # NUTS amplifies rounding differences (a case of this generator: 1e-13 after 4 iterations, 3e-6 after 10): joint chains are
+        # compared over at most 9 iterations, the BART block alone over up to 50
+        warmup = int(g.integers(2, 6)); it = warmup + int(g.integers(3, 5))
+    args = make_sampler_args(y, xb, X=x4[:, None], groups=groups, family="binomial" if binary else "gaussian", iter=it, warmup=warmup,
+                             skip=skip, weights=weights, x_test=xb[:n_test].copy() if n_test else None, bart_args=bart_args,
+                             stan_args={"hmc_mode": int(g.integers(0, 2))} if joint else None)
+    capacity = bool(g.random() < 0.1)
+    if capacity:
+        args.node_capacity = 3000          # (the control code's global-memory path)
+    return args, joint, dict(n=n, p=p, binary=binary, ranef=ranef, deep=deep, joint=joint, weights=weights is not None, capacity=capacity, **bart_args)
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("seed", range(160))
+def test_random_configuration(oracle_lib, hip_lib, seed, path):
+    args, joint, what = random_case(seed)
+    rt = 0 if joint else 1
+    a = run_chain(oracle_lib, "orc_", args, results_type=rt)
+    # (the oracle takes no hmc_mode: both modes must reproduce it)
+    b = run_chain(hip_lib, "s4b_", args, results_type=rt, tree_path=path)
+    # (the lagged launch has no weighted instantiation and a smaller LDS budget for the node tables: there the sampler reports
+    # the path it took instead — s4b_get_tree_path returns both)
+    assert b["tree_path"][0] == path and (b["tree_path"][1] == path or what["weights"] or what["capacity"]), (what, b["tree_path"])
+    try:
+        assert_chain_parity(a, b, stan=joint)
+    except AssertionError as e:
+        raise AssertionError(f"seed {seed} on the {path} path, case {what}: {e}") from e

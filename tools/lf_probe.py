@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import c5_case, make_sampler   # noqa: E402
 from stan4bart_amd._lib import load_library   # noqa: E402
 hlib = load_library()
-for n in (1000000, 10000000):
+for n in ([int(float(v)) for v in sys.argv[1:]] or (1000000, 10000000)):
     from stan4bart_amd import GroupTerm, make_sampler_args
     g = np.random.default_rng(5)
     xb = np.empty((n, 9), order="F")
