@@ -9,9 +9,11 @@ t0 = time.time()
 # 1. long BART-only parity run (speculation must never change the stream)
 args, _ = friedman_case(n=20000, T=50, warmup=150, iter=300)
 a = run_chain(orc, "orc_", args, results_type=1)
-b = run_chain(hip, "s4b_", args, results_type=1)
-assert_chain_parity(a, b, stan=False)
-print("long BART parity ok:", len(a["trace"]), "tree updates, accept rate", (a["trace"][:, 1] == 1).mean().round(3), time.time() - t0)
+for path in ("fused", "two-kernel", "lagged"):
+    b = run_chain(hip, "s4b_", args, results_type=1, tree_path=path)
+    assert b["tree_path"][1] == path
+    assert_chain_parity(a, b, stan=False)
+    print("long BART parity ok on the", path, "path:", len(a["trace"]), "tree updates, accept rate", (a["trace"][:, 1] == 1).mean().round(3), round(time.time() - t0, 1), "s", flush=True)
 # 2. soak: many iterations at n = 1e5, joint chain, gaussian and binary
 for binary in (False, True):
     from stan4bart_amd import GroupTerm, generate_friedman_data, make_sampler_args, RRng
