@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Tuning probe for the BART sweep on the GPU box: Friedman-like data from numpy's generator (fast to make; the sweep's cost
 does not depend on which generator made x), a few Gibbs iterations, then s4b_profile_sweep.  Environment switches of the
-library apply (S4B_FUSED, S4B_GRIDF, S4B_GRID, S4B_LIB_PATH=.../libs4b_timing.so for the in-kernel phase timers).
+library apply (S4B_GRIDF, S4B_GRID, S4B_LIB_PATH=.../libs4b_timing.so for the in-kernel phase timers); --path picks the tree update.
     python tools/step_probe.py --n 1000000 --p 50 --trees 200 --sweeps 3"""
 import argparse
 import json
@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--trees", type=int, default=200)
     ap.add_argument("--sweeps", type=int, default=3)
     ap.add_argument("--iters", type=int, default=6)
+    ap.add_argument("--path", default="auto", choices=["auto", "two-kernel", "fused", "lagged"])
     a = ap.parse_args()
     from stan4bart_amd import RRng, make_sampler_args
     from stan4bart_amd._lib import load_library
@@ -36,6 +37,7 @@ def main():
     rng = RRng(4321)
     args.seed = int(rng.sample_int(2147483647, 1)[0])
     s = Sampler(load_library(), "s4b_", args, rng.state)
+    s.set_tree_path(a.path)
     s.run(a.iters, True, 0)
     prof = s.profile_sweep(a.sweeps)
     s.free()
