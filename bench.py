@@ -29,7 +29,13 @@ import argparse
 import ctypes
 import json
 import os
+
+# ROCr / RCCL read their environment when the runtime initialises: set it before anything can touch HIP (the host driver of this
+# pool only supports dmabuf IPC; without this RCCL fails with `hipIpcGetMemHandle: invalid argument`)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import shutil
+import socket
 import subprocess
 import sys
 import time
@@ -217,6 +223,38 @@ def reference_r_leg(n, p, trees, iters):
     return {"status": "bench/reference_cpu.R did not report (is the stan4bart package installed?): " + out.stderr.strip()[-300:], "script": "bench/reference_cpu.R"}
 
 
+def self_launch(a, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher: the chain fan-out of the reference (R/stan4bart_fit.R:498-533 starts one
+    worker process per chain) needs one process per GPU, so this process — BEFORE any GPU call — starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a child (never exec: a process that has
+    touched the GPU must not be replaced) and relays its JSON line and exit code."""
+    if not a.emul:
+        import torch
+        have = torch.cuda.device_count()        # (counting devices does not initialise the GPU)
+        if have < a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but only {have} GPU(s) are visible: one chain per GPU needs one GPU per rank")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [("--num-obs" if x == "--n" else x) for x in argv]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+    for ln in child.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if child.returncode != 0:
+        raise SystemExit(child.returncode)
+    if len(lines) != 1:
+        raise SystemExit(f"the {a.gpus}-rank run printed {len(lines)} JSON lines, expected one")
+    rec = json.loads(lines[0])
+    if rec.get("n_gpus") != a.gpus:
+        raise SystemExit(f"the run reports n_gpus = {rec.get('n_gpus')}, asked for --gpus {a.gpus}")
+    print(lines[0])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,6 +276,10 @@ def main():
                     help="TEST ONLY (pytest -m 'not gpu'): run the N-rank plumbing of this script over the CPU emulation of the device layer "
                          "(tests/emul) and gloo; prints a line whose numbers mean nothing")
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a, sys.argv[1:])
     t_start = time.perf_counter()
 
     import torch
@@ -249,7 +291,7 @@ def main():
     # S4B_BENCH_BACKEND=gloo + S4B_BENCH_ONE_DEVICE=1: rehearsal of the N-rank path on a single-GPU box (all ranks share
     # device 0, the collectives run over gloo); the driver's real runs use the default: one GPU per rank, RCCL
     rank0, local0, world0 = dist_env()
-    if world0 != a.gpus and world0 > 1:
+    if world0 != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world0}")
     one_device = bool(os.environ.get("S4B_BENCH_ONE_DEVICE"))
     if not a.emul:
@@ -458,6 +500,8 @@ def main():
             extra["config2"] = {"workload": "Friedman n=1e5, p=10, ntree=200, fixed effects only (BASELINE config 2)",
                                 "gpu_iters_per_sec": v2g, "gpu_seconds": s2g, "cpu_port_iters_per_sec": v2c, "cpu_seconds": s2c, "cpu_cores": 1}
             rec["extra_configs"] = extra
+        if rec["n_gpus"] != a.gpus:
+            raise SystemExit(f"internal: n_gpus {rec['n_gpus']} != --gpus {a.gpus}")
         print(json.dumps(rec))
     if world > 1:
         torch.distributed.destroy_process_group()

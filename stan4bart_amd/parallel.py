@@ -8,6 +8,10 @@ data-path collective because the chains share nothing.
 from __future__ import annotations
 
 import os
+
+# read by ROCr when the runtime initialises, i.e. it must be in place before anything touches HIP (the host driver only
+# supports dmabuf IPC; RCCL fails with `hipIpcGetMemHandle: invalid argument` without it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 from typing import Callable, Optional
 
 import numpy as np
@@ -33,7 +37,6 @@ def init_process_group(backend: Optional[str] = None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

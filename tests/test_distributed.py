@@ -113,3 +113,51 @@ def test_bench_refuses_more_ranks_than_gpus():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=300, env=env, cwd=ROOT)
     assert out.returncode != 0 and ("MI355X" in out.stderr or "GPU" in out.stderr)
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def test_bench_launches_its_own_ranks(emul_lib):
+    """`python bench.py --gpus 2` with NO launcher on the command line (the form the driver uses for N = 1): the parent starts the
+    two ranks itself (torch.distributed.run as a child process, before anything touches the GPU), relays the one JSON line and
+    checks n_gpus == --gpus.  Reference: the chain fan-out of R/stan4bart_fit.R:498-533."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--burn-in", "4", "--n", "300", "--p", "10",
+           "--trees", "5", "--emul", "--no-extra-configs", "--no-cpu-baseline", "--target-n", "0"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=dict(_clean_env(), OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["chains"] == 2 and len(rec["per_chain_by_rank"]) == 2
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """--gpus N with fewer than N visible GPUs exits non-zero — it must never run fewer chains than asked for and print n_gpus: 1"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300, env=_clean_env(), cwd=ROOT)
+    assert out.returncode != 0 and "GPU" in out.stderr and not any(ln.startswith("{") for ln in out.stdout.splitlines())
+
+
+def test_bench_refuses_world_size_mismatch():
+    """under a launcher, WORLD_SIZE must equal --gpus (also WORLD_SIZE = 1 with --gpus 2)"""
+    import subprocess
+    env = dict(_clean_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29998")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--emul"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr
+
+
+def test_rocr_environment_is_set_before_any_gpu_call():
+    """HSA_ENABLE_IPC_MODE_LEGACY is read when ROCr initialises: bench.py and parallel.py must set it at import time, not after
+    torch.cuda.* has run"""
+    import subprocess
+    code = ("import os; os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None); import stan4bart_amd.parallel; "
+            "assert os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'")
+    assert subprocess.run([sys.executable, "-c", code], cwd=ROOT).returncode == 0
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY"') < src.index("import numpy")
