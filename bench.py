@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--no-hmc-mode1", action="store_true")
     ap.add_argument("--profile-sweeps", type=int, default=2)
-    ap.add_argument("--tree-path", default="auto", choices=["auto", "two-kernel", "fused", "lagged"])
+    ap.add_argument("--tree-path", default="auto", choices=["auto", "two-kernel", "fused", "lagged", "persistent"])
     ap.add_argument("--target-n", type=int, default=10_000_000,
                     help="also measure the sweep kernel at north_star's roofline-target size (0 = skip; N = 1 only)")
     ap.add_argument("--emul", action="store_true",

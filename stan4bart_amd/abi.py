@@ -429,10 +429,11 @@ class Sampler:
         if fn is not None:          # (the CPU oracle has no such notion)
             self._check(fn(self._h, int(chains)))
 
-    TREE_PATHS = {"auto": 0, "two-kernel": 1, "fused": 2, "lagged": 3}
+    TREE_PATHS = {"auto": 0, "two-kernel": 1, "fused": 2, "lagged": 3, "persistent": 4}
 
     def set_tree_path(self, path):
-        """Device code of a tree update: "auto", "two-kernel" (k_tree + k_control), "fused" (k_step) or "lagged" (k_lag)."""
+        """Device code of a tree update: "auto", "two-kernel" (k_tree + k_control), "fused" (k_step), "lagged" (k_lag) or "persistent"
+        (k_sweep: one launch per sweep)."""
         fn = getattr(self._lib, self._pfx + "set_tree_path", None)
         if fn is not None:          # (the CPU oracle has one path)
             self._check(fn(self._h, int(self.TREE_PATHS.get(path, path))))

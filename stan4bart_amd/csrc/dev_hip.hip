@@ -568,6 +568,7 @@ __device__ __forceinline__ void proposal_store(const Proposal& p, Proposal* dst,
   if (lane < 20) ((int*)dst)[lane] = w;
 }
 
+#ifndef S4B_SWEEP_TU   // (dev_sweep.hip compiles this file up to k_sweep only: see the end of the device section)
 __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int next) {
   __shared__ ControlShared S;
   const int lane = threadIdx.x & 63;
@@ -869,8 +870,15 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
     } }
 #endif
 }
+#endif   // S4B_SWEEP_TU
 
 #include "dev_step.inc"
+// The persistent sweep is compiled in a translation unit of its own (dev_sweep.hip includes this file with S4B_SWEEP_TU: the
+// helpers above + dev_step.inc + the kernel), with -mllvm -disable-machine-licm: the kernel is one long loop over the trees, and
+// hoisting every loop-invariant constant and mask out of it costs ~190 more spilled vector registers than it saves instructions.
+// Here: its declarations only.
+#include "dev_sweep.inc"
+#ifndef S4B_SWEEP_TU
 #include "dev_lag.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -1837,6 +1845,7 @@ class DevHip {
     if (lagExec_) (void)hipGraphExecDestroy(lagExec_);
     if (lagGraph_) (void)hipGraphDestroy(lagGraph_);
     if (pinnedLag_) (void)hipHostFree(pinnedLag_);
+    if (sweepStatus_) (void)hipHostFree(sweepStatus_);
     for (void* p : allocs_) (void)hipFree(p);
     if (pinned_) (void)hipHostFree(pinned_);
     if (pinnedAcc_) (void)hipHostFree(pinnedAcc_);
@@ -1963,6 +1972,21 @@ class DevHip {
         lag_.cells = zalloc<uint8_t>((size_t)3 * a.npad); lag_.stat = zalloc<int32_t>(LS_WORDS);
         HIP_OK(hipHostMalloc(&pinnedLag_, sizeof(int32_t) * 16, hipHostMallocDefault));
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLag_));
+      }
+      // persistent sweep (dev_sweep.inc): ONE launch per sweep, the residual in registers, every workgroup deciding redundantly.
+      // Needs every quad of a thread in registers (F_PF of them), all gridF workgroups resident at once (one per CU: they wait for
+      // each other inside the launch) and no weights.
+      {
+        hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, device_));
+        sweepOk_ = fusedOk_ && d.weights == nullptr && perThread <= F_PF && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount &&
+                   sweep_lds_bytes() + 40 * 1024 <= 160 * 1024;
+        if (sweepOk_) {
+          xbuf_ = zalloc<unsigned long long>((size_t)XC_RING * XC_BUF_WORDS);
+          HIP_OK(hipHostMalloc(&sweepStatus_, 64, hipHostMallocCoherent | hipHostMallocMapped));
+          sweepStatus_[0] = -1;
+          { void* dp = nullptr; HIP_OK(hipHostGetDevicePointer(&dp, sweepStatus_, 0)); sweepStatusDev_ = (int32_t*)dp; }
+          HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
+        }
       }
       choose_path();
     }
@@ -2144,7 +2168,28 @@ class DevHip {
       if (dbgSweeps_ % 20 == 0) fprintf(stderr, "S4B in-loop sweep GPU time: %.3f ms avg over %d\n", dbgSweepMs_ / dbgSweeps_, dbgSweeps_);
     }
   }
+  // persistent path: one k_sweep launch per sweep; the status word (host-visible) says how far it got: T + 1 = the whole sweep,
+  // t in 1..T = k_step launches t..T finish it (a tree outgrew the wave-register control path), 0 = nothing done (tree 0 did)
+  void sweep_persistent_one() {
+    HIP_OK(hipMemsetAsync(xbuf_, 0, sizeof(unsigned long long) * (size_t)XC_RING * XC_BUF_WORDS, stream_));
+    sweepStatus_[0] = -1;
+    hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, SweepArgs{xbuf_, sweepStatusDev_}); ++launches_;
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(stream_));
+    const int st = sweepStatus_[0];
+    ++sweepCount_;
+    if (st == T_ + 1) return;
+    if (st < 0 || st > T_ + 1) throw std::runtime_error("persistent tree sweep: the launch did not complete (a workgroup timed out waiting for the others — is the device shared?)");
+    ++sweepHandOvers_;
+    if (st == 0) { sweep_fused_one(); return; }
+    for (int t = st; t <= T_; ++t) { launch_step(t); ++launches_; }
+    if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_));
+  }
   void sweep_impl(int thin) {
+    if (path_ == PATH_SWEEP) {
+      for (int k = 0; k < thin; ++k) { sweep_persistent_one(); if (binary_) launch_latents(); }
+      return;
+    }
     if (path_ == PATH_LAG) {
       for (int k = 0; k < thin; ++k) { sweep_lag_one(); if (binary_) launch_latents(); }
       return;
@@ -2337,7 +2382,7 @@ class DevHip {
   }
   // tree-update path: 0 automatic, 1 two kernels per tree (k_tree + k_control), 2 fused (k_step), 3 lagged (k_lag)
   void set_tree_path(int path) {
-    if (path < 0 || path > 3) throw std::invalid_argument("tree path must be 0 (automatic), 1 (two-kernel), 2 (fused) or 3 (lagged)");
+    if (path < 0 || path > 4) throw std::invalid_argument("tree path must be 0 (automatic), 1 (two-kernel), 2 (fused), 3 (lagged) or 4 (persistent)");
     pathReq_ = path; choose_path();
   }
   void get_tree_path(int32_t out[2]) const { out[0] = pathReq_; out[1] = path_; }
@@ -2350,7 +2395,9 @@ class DevHip {
     // automatic: the fused launch while a tree update is latency-bound (few quads per thread), two kernels per tree beyond and when
     // three or more chains share the device.  The lagged path is never chosen automatically: measured on MI355X it does not beat
     // them (every fifth to tenth launch is a repair, and the pass of a 254-VGPR kernel is latency-bound)
-    if (want == 0) want = sharing_ >= 3 ? PATH_TWO : (fusedAuto_ ? PATH_FUSED : PATH_TWO);
+    // The persistent sweep wherever it applies and the chain has the device to itself (its workgroups wait for each other).
+    if (want == 0) want = sharing_ >= 3 ? PATH_TWO : ((sweepOk_ && sharing_ <= 1) ? PATH_SWEEP : (fusedAuto_ ? PATH_FUSED : PATH_TWO));
+    if (want == PATH_SWEEP && !sweepOk_) want = fusedOk_ ? PATH_FUSED : PATH_TWO;
     if (want == PATH_LAG && !lagOk_) want = fusedOk_ ? PATH_FUSED : PATH_TWO;
     if (want == PATH_FUSED && !fusedOk_) want = PATH_TWO;
     if (want == path_) return;
@@ -2426,7 +2473,50 @@ class DevHip {
     float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_));
     out[6] = ms * 1000.0 / nSweeps;
   }
+  // persistent path: the sweep IS one launch; out[0] = its average duration (HIP events on the sampler's stream), out[1] = sweeps that
+  // were handed over to k_step so far / all persistent sweeps so far (out[4]), out[6] = wall time per sweep without events
+  void profile_sweep_persistent(int nSweeps, int thin, double* out) {
+    double sum = 0; int cnt = 0;
+    for (int sIdx = 0; sIdx < nSweeps * thin; ++sIdx) {
+      const int64_t ho = sweepHandOvers_;
+      HIP_OK(hipMemsetAsync(xbuf_, 0, sizeof(unsigned long long) * (size_t)XC_RING * XC_BUF_WORDS, stream_));
+      HIP_OK(hipEventRecord(evStart_, stream_));
+      sweepStatus_[0] = -1;
+      hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, SweepArgs{xbuf_, sweepStatusDev_}); ++launches_;
+      HIP_OK(hipEventRecord(evStop_, stream_));
+      sync();
+      const int st = sweepStatus_[0];
+      ++sweepCount_;
+      if (st < 0 || st > T_ + 1) throw std::runtime_error("persistent tree sweep: the launch did not complete");
+      if (st != T_ + 1) {
+        ++sweepHandOvers_;
+        if (st == 0) sweep_fused_one();
+        else { for (int t = st; t <= T_; ++t) { launch_step(t); ++launches_; }
+               if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_)); }
+      }
+      if (binary_) launch_latents();
+      sync();
+      if (ho == sweepHandOvers_) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_)); sum += ms * 1000.0; ++cnt; }
+    }
+#ifdef S4B_SWEEP_TIMING
+    { unsigned long long h[24]; sweep_timing_fetch(h);
+      { const double kp = h[13] ? 1.0 / (100.0 * (double)h[13]) : 0.0;
+        fprintf(stderr, "SWEEP pass of wave 3 (us after the barrier, %llu passes with both halves and <= 8 bins): root columns here %.2f | first level routed %.2f | deeper levels %.2f | arithmetic + relabel %.2f | block reduction + publish %.2f\n",
+                h[13], h[16] * kp, h[17] * kp, h[18] * kp, h[19] * kp, h[20] * kp); }
+      const double k = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0;
+      fprintf(stderr, "SWEEP workgroup 100, us after it left the previous pass (avg over %llu steps, %.2f bins): wave 0 at the step top %.2f | gather done %.2f -> totals seen %.2f -> verdict %.2f -> decide + tables %.2f | at the barrier: wave 0 %.2f, image wave %.2f, loaders %.2f | barrier passed %.2f | pass + publish done %.2f | (next step) images drawn %.2f\n",
+              h[0], h[0] ? (double)h[12] / (double)h[0] : 0.0, h[11] * k, h[1] * k, h[2] * k, h[3] * k, h[4] * k, h[5] * k, h[6] * k, h[10] * k, h[7] * k, h[8] * k, h[9] * k); }
+#endif
+    out[0] = cnt ? sum / cnt : 0.0; out[3] = cnt;
+    out[1] = (double)sweepHandOvers_; out[4] = (double)sweepCount_;
+    out[2] = 0.0; out[5] = 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int sIdx = 0; sIdx < nSweeps; ++sIdx) sweep(thin);
+    sync();
+    out[6] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / nSweeps;
+  }
   void profile_sweep(int nSweeps, int thin, double* out) {
+    if (path_ == PATH_SWEEP) { profile_sweep_persistent(nSweeps, thin, out); return; }
     if (path_ == PATH_LAG) { profile_sweep_lag(nSweeps, thin, out); return; }
     if (useFused_) { profile_sweep_fused(nSweeps, thin, out); return; }
     const int perSweep = 2 * T_ * thin + thin;
@@ -2726,7 +2816,9 @@ class DevHip {
   int device_ = 0; hipStream_t stream_ = nullptr; hipEvent_t evStart_ = nullptr, evStop_ = nullptr;
   int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1; bool binary_ = false;
   size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0, ldsLag_ = 0; bool useFused_ = false, fusedAuto_ = false, fusedOk_ = false, lagOk_ = false;
-  enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_LAG = 3 };
+  enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_LAG = 3, PATH_SWEEP = 4 };
+  bool sweepOk_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
+  int64_t sweepCount_ = 0, sweepHandOvers_ = 0;
   int pathReq_ = 0, path_ = 0, sharing_ = 1;
   LagArrays lag_{}; int32_t* pinnedLag_ = nullptr; hipGraph_t lagGraph_ = nullptr; hipGraphExec_t lagExec_ = nullptr; int lagCaptured_ = 0, lagTrace_ = -1;
   double lagRepairs_ = 4.0; int64_t lagLaunchesUsed_ = 0, lagBubbles_ = 0, lagSlow_ = 0, lagSeq_ = 0, lagSweeps_ = 0, lagTopUps_ = 0;
@@ -2743,7 +2835,10 @@ class DevHip {
   int64_t launches_ = 0;
 };
 
+#endif   // S4B_SWEEP_TU
 }  // namespace s4b
 
+#ifndef S4B_SWEEP_TU
 #define S4B_DEV s4b::DevHip
 #include "c_api.inc"
+#endif
