@@ -1974,11 +1974,11 @@ class DevHip {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLag_));
       }
       // persistent sweep (dev_sweep.inc): ONE launch per sweep, the residual in registers, every workgroup deciding redundantly.
-      // Needs every quad of a thread in registers (F_PF of them), all gridF workgroups resident at once (one per CU: they wait for
+      // Needs every quad of a pass thread in registers (SW_PF of them, 5 pass waves per workgroup), all gridF workgroups resident at once (one per CU: they wait for
       // each other inside the launch) and no weights.
       {
         hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, device_));
-        sweepOk_ = fusedOk_ && d.weights == nullptr && perThread <= F_PF && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount &&
+        sweepOk_ = fusedOk_ && d.weights == nullptr && nQuads <= (int64_t)(a.gridF - 1) * SW_PT * SW_PF && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount &&
                    sweep_lds_bytes() + 40 * 1024 <= 160 * 1024;
         if (sweepOk_) {
           xbuf_ = zalloc<unsigned long long>((size_t)XC_RING * XC_BUF_WORDS);
@@ -2500,12 +2500,9 @@ class DevHip {
     }
 #ifdef S4B_SWEEP_TIMING
     { unsigned long long h[24]; sweep_timing_fetch(h);
-      { const double kp = h[13] ? 1.0 / (100.0 * (double)h[13]) : 0.0;
-        fprintf(stderr, "SWEEP pass of wave 3 (us after the barrier, %llu passes with both halves and <= 8 bins): root columns here %.2f | first level routed %.2f | deeper levels %.2f | arithmetic + relabel %.2f | block reduction + publish %.2f\n",
-                h[13], h[16] * kp, h[17] * kp, h[18] * kp, h[19] * kp, h[20] * kp); }
       const double k = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0;
-      fprintf(stderr, "SWEEP workgroup 100, us after it left the previous pass (avg over %llu steps, %.2f bins): wave 0 at the step top %.2f | gather done %.2f -> totals seen %.2f -> verdict %.2f -> decide + tables %.2f | at the barrier: wave 0 %.2f, image wave %.2f, loaders %.2f | barrier passed %.2f | pass + publish done %.2f | (next step) images drawn %.2f\n",
-              h[0], h[0] ? (double)h[12] / (double)h[0] : 0.0, h[11] * k, h[1] * k, h[2] * k, h[3] * k, h[4] * k, h[5] * k, h[6] * k, h[10] * k, h[7] * k, h[8] * k, h[9] * k); }
+      fprintf(stderr, "SWEEP workgroup 100 (avg over %llu steps, %.2f bins, %llu routed after the decision) | pass waves, us after the previous publish: totals gathered (wave 3) %.2f; wave 4: images there %.2f, routed %.2f, tables + proposal there %.2f, arithmetic done %.2f; published (wave 3) = step %.2f | decider, us after its previous step: totals seen %.2f, verdict %.2f, tables out %.2f, step end %.2f | image wave 1, us after its previous image: starts drawing %.2f, drawn %.2f\n",
+              h[0], h[0] ? (double)h[7] / (double)h[0] : 0.0, h[8], h[1] * k, h[2] * k, h[3] * k, h[4] * k, h[5] * k, h[6] * k, h[9] * k, h[10] * k, h[11] * k, h[12] * k, h[13] * k, h[14] * k); }
 #endif
     out[0] = cnt ? sum / cnt : 0.0; out[3] = cnt;
     out[1] = (double)sweepHandOvers_; out[4] = (double)sweepCount_;
