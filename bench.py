@@ -46,7 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
-DOMINANT = {"fused": "k_step", "two-kernel": "k_tree", "lagged": "k_lag"}
+DOMINANT = {"fused": "k_step", "two-kernel": "k_tree", "persistent": "k_sweep"}
 
 
 def pin_rank_to_cores(local_rank: int, ranks_on_node: int):
@@ -96,10 +96,11 @@ def case_from_design(d, p, trees, device, warmup, iters, ranef=True, keep_fits=F
                              bart_args={"n.trees": trees}, device=device, stan_args={"hmc_mode": hmc_mode})
 
 
-def sweep_roofline(prof, path, n, trees, lag):
+def sweep_roofline(prof, path, n, trees):
     """Roofline record of the dominant kernel of one sweep.  Algorithmic bytes of a tree update: R read 8 + R write 8 + leaf id of
     the finished tree 2 + leaf id of the tree whose statistics are gathered 2 + binned predictor 2 = 22 B per observation."""
-    per_launch = 22.0 * n
+    # (the persistent path runs a whole sweep — `trees` tree updates — in ONE launch of k_sweep: its launch does `trees` times the work)
+    per_launch = 22.0 * n * (trees if path == "persistent" else 1)
     rec = {"bound": "hbm", "kernel": DOMINANT[path], "tree_path": path, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "avg_launch_us": prof["stats_us"], "algorithmic_bytes_per_launch": per_launch,
            "timing": "HIP events around every launch on the sampler's stream (adds ~2 us per launch; profiles/ has rocprofv3)",
@@ -107,15 +108,19 @@ def sweep_roofline(prof, path, n, trees, lag):
            "achieved_GBs_whole_sweep": per_launch * trees / (prof["sweep_wall_us"] * 1e-6) / 1e9}
     rec["achieved"] = per_launch / (prof["stats_us"] * 1e-6) / 1e9
     rec["frac"] = rec["achieved"] / HBM_PEAK_GBS
+    if path == "persistent":
+        rec["tree_updates_per_launch"] = trees
+        rec["avg_tree_update_us"] = prof["stats_us"] / trees
+        rec["sweeps_handed_over_to_k_step"] = prof["control_us"]     # a tree outgrew the 64 node slots of the wave-register control path
+        rec["persistent_sweeps"] = prof["launches"][1]
+        rec["note"] = ("algorithmic bytes (SURVEY 8d: 22 B per observation and tree update) / launch duration; the launch itself moves far less: "
+                       "the residual stays in registers for the whole sweep (per tree update 2 B leaf id + 2-6 B predictor columns read, 2 B written under an accepted move)")
+        return rec
     if path == "two-kernel":
         rec["separate_control_kernel_us"] = prof["control_us"]
         rec["last_launch_of_sweep_us"] = prof["apply_us"]
     elif path == "fused":
         rec["last_launch_of_sweep_us"] = prof["apply_us"]
-    else:   # lagged: launches per sweep and repairs per sweep come back in the control / apply slots
-        rec["launches_per_sweep"] = prof["control_us"]
-        rec["repair_launches_per_sweep"] = prof["apply_us"]
-        rec["lag_stats"] = lag
     return rec
 
 
@@ -146,7 +151,7 @@ def target_roofline_leg(lib, n, p, trees, device, sweeps):
     path = s.get_tree_path()[1]
     prof = s.profile_sweep(sweeps)
     lf = s.profile_leapfrog(10)
-    rec = sweep_roofline(prof, path, n, trees, s.get_lag_stats())
+    rec = sweep_roofline(prof, path, n, trees)
     s.free()
     rec["workload"] = f"Friedman n={n}, p={p}, ntree={trees} (north_star roofline target config)"
     rec["hmc"] = {"kernel": "k_stan_fused (direct), K=2, z=3", "bound": "hbm", "achieved": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9,
@@ -269,7 +274,7 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--no-hmc-mode1", action="store_true")
     ap.add_argument("--profile-sweeps", type=int, default=2)
-    ap.add_argument("--tree-path", default="auto", choices=["auto", "two-kernel", "fused", "lagged", "persistent"])
+    ap.add_argument("--tree-path", default="auto", choices=["auto", "two-kernel", "fused", "persistent"])
     ap.add_argument("--target-n", type=int, default=10_000_000,
                     help="also measure the sweep kernel at north_star's roofline-target size (0 = skip; N = 1 only)")
     ap.add_argument("--emul", action="store_true",
@@ -377,9 +382,8 @@ def main():
     # the only collective: chain summaries (last sigma, per-rank set-up seconds, per-rank timed seconds)
     summ = all_gather_array(np.array([float(out["bart"]["sigma"][-1]), t_design - t_start, t_created - t_design, dt, float(len(cores))]))
 
-    prof = lf = probe = lag = None
+    prof = lf = probe = None
     if rank == 0 and not a.emul:
-        lag = sampler.get_lag_stats()
         prof = sampler.profile_sweep(a.profile_sweeps)
         lf = sampler.profile_leapfrog(20)
         po = (ctypes.c_double * 4)()   # measured streaming ceiling of this device (read-only and in-place update over 1 GB)
@@ -447,7 +451,7 @@ def main():
                     traffic_note = "replayed from profiles/pmc_traffic.json (" + str(ent.get("kernel")) + "), not measured in this run"
             except (OSError, ValueError):
                 pass
-            rf = sweep_roofline(prof, tree_path, n, a.trees, lag)
+            rf = sweep_roofline(prof, tree_path, n, a.trees)
             rf["traffic"], rf["traffic_note"] = traffic, traffic_note
             rf["measured_stream"] = probe
             rf["frac_of_measured_update_stream"] = (rf["achieved"] / probe["update_in_place_GBs"]) if probe else None

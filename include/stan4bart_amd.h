@@ -267,21 +267,23 @@ int S4B_FN(get_leaf_assignment)(s4b_sampler* s, int32_t tree, int32_t* out);
  * per-bin sums (1e-15 relative).  May be called at any time between runs. */
 int S4B_FN(set_device_sharing)(s4b_sampler* s, int32_t chains);
 /* Not a reference routine.  Which device code runs a tree update: 0 automatic (default), 1 two kernels per tree (k_tree + k_control),
- * 2 one fused launch per tree (k_step), 3 lagged (k_lag: the O(N) pass of a launch never waits for a decision; the decision of the
- * tree before runs beside it and corrects its statistics through an integer contingency table).  A request the sampler cannot
- * honour (weights or a node capacity beyond the LDS budget for 3, more than 255 quads per thread for 2) falls back to the next
- * path down.  The same chain on every path (see set_device_sharing).  May be called at any time between runs.
- * get_tree_path: out[0] = the request, out[1] = the path in effect (1..3). */
+ * 2 one fused launch per tree (k_step), 4 persistent (k_sweep: ONE launch per
+ * sweep, the residual in registers, bin partials exchanged through order-free integer atomics; the automatic choice wherever it
+ * applies: no weights, at most 16 observations per pass thread (n <= 1.3e6), the chain has the device to itself).  A request the
+ * sampler cannot honour (more than 255 quads per thread for 2, the conditions above for 4) falls back to the next path down; get_tree_path reports the path in effect.  The same chain on every
+ * path (see set_device_sharing).  May be called at any time between runs.
+ * get_tree_path: out[0] = the request, out[1] = the path in effect (1, 2 or 4).  (3 was the lagged launch of
+ * an earlier revision: removed, the value is rejected.) */
 int S4B_FN(set_tree_path)(s4b_sampler* s, int32_t path);
 int S4B_FN(get_tree_path)(s4b_sampler* s, int32_t out[2]);
-/* lagged path only (zeros otherwise): out = {sweeps, launches used per sweep, repair launches per sweep (a speculated proposal image
- * did not hold), slow (one step at a time) passes, decisions without a statistics pass beside them, host top-ups} since creation */
-int S4B_FN(get_lag_stats)(s4b_sampler* s, double out[6]);
 /* counters: {log-density gradient evaluations, tree updates, device kernel launches} */
 int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
 /* diagnostics of the one-launch O(N) sums of the Stan block (k_stan_fused): out = {evaluations, evaluations repeated in plain
  * doubles because the fixed-point range check failed (first evaluation, rescaled response, trajectory far outside the typical set)} */
 int S4B_FN(get_fused_stats)(s4b_sampler* s, int64_t out[2]);
+/* persistent tree path only (zeros otherwise): out = {sweeps run by k_sweep, of which handed over to k_step launches part-way because a
+ * tree outgrew the 64 node slots of the wave-register control path} since creation */
+int S4B_FN(get_sweep_stats)(s4b_sampler* s, int64_t out[2]);
 /* extension: how the Stan block evaluates the O(N) part of the log density (stan_control.hmc_mode): 0 = sufficient statistics
  * gathered once per Gibbs iteration, 1 = one device evaluation per leapfrog (the reference's cost model).  A sampler created
  * with mode 0 may be switched to 1 and back between runs (same posterior, same draws up to rounding); one created with mode 1

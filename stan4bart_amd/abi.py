@@ -275,7 +275,7 @@ class Sampler:
             "get_leaf_assignment": [vp, i32, ip], "get_counters": [vp, C.POINTER(i64)], "get_nuts_stats": [vp, dp],
             "profile_sweep": [vp, i32, dp], "profile_leapfrog": [vp, i32, dp],
             "set_progress": [vp, PROGRESS, vp], "set_device_sharing": [vp, i32],
-            "set_tree_path": [vp, i32], "get_tree_path": [vp, ip], "get_lag_stats": [vp, dp], "get_fused_stats": [vp, C.POINTER(i64)], "set_hmc_mode": [vp, i32], "get_hmc_mode": [vp, ip],
+            "set_tree_path": [vp, i32], "get_tree_path": [vp, ip], "get_fused_stats": [vp, C.POINTER(i64)], "get_sweep_stats": [vp, C.POINTER(i64)], "set_hmc_mode": [vp, i32], "get_hmc_mode": [vp, ip],
         }
         for name, argtypes in sig.items():
             fn = getattr(self._lib, self._pfx + name, None)
@@ -429,11 +429,11 @@ class Sampler:
         if fn is not None:          # (the CPU oracle has no such notion)
             self._check(fn(self._h, int(chains)))
 
-    TREE_PATHS = {"auto": 0, "two-kernel": 1, "fused": 2, "lagged": 3, "persistent": 4}
+    TREE_PATHS = {"auto": 0, "two-kernel": 1, "fused": 2, "persistent": 4}
 
     def set_tree_path(self, path):
-        """Device code of a tree update: "auto", "two-kernel" (k_tree + k_control), "fused" (k_step), "lagged" (k_lag) or "persistent"
-        (k_sweep: one launch per sweep)."""
+        """Device code of a tree update: "auto", "two-kernel" (k_tree + k_control), "fused" (k_step) or "persistent" (k_sweep: one
+        launch per sweep)."""
         fn = getattr(self._lib, self._pfx + "set_tree_path", None)
         if fn is not None:          # (the CPU oracle has one path)
             self._check(fn(self._h, int(self.TREE_PATHS.get(path, path))))
@@ -447,14 +447,6 @@ class Sampler:
         self._check(fn(self._h, _ip(out)))
         names = {v: k for k, v in self.TREE_PATHS.items()}
         return (names[int(out[0])], names[int(out[1])])
-
-    def get_lag_stats(self) -> dict:
-        out = np.zeros(6, dtype=np.float64)
-        fn = getattr(self._lib, self._pfx + "get_lag_stats", None)
-        if fn is not None:
-            self._check(fn(self._h, _dp(out)))
-        return {"sweeps": out[0], "launches_per_sweep": out[1], "repairs_per_sweep": out[2], "slow_passes": out[3],
-                "decisions_alone": out[4], "host_top_ups": out[5]}
 
     def set_hmc_mode(self, mode: int):
         self._check(self._f("set_hmc_mode")(self._h, int(mode)))
@@ -474,6 +466,15 @@ class Sampler:
         if fn is not None:
             self._check(fn(self._h, out))
         return int(out[0]), int(out[1])
+
+    def get_sweep_stats(self):
+        """(sweeps run by the persistent kernel, of which handed over to k_step part-way) since creation."""
+        fn = getattr(self._lib, self._pfx + "get_sweep_stats", None)
+        if fn is None:
+            return (0, 0)
+        out = (C.c_int64 * 2)()
+        self._check(fn(self._h, out))
+        return (int(out[0]), int(out[1]))
 
     def set_trace(self, enable: bool):
         self._check(self._f("set_trace")(self._h, int(enable)))

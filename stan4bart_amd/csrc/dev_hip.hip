@@ -879,7 +879,6 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
 // Here: its declarations only.
 #include "dev_sweep.inc"
 #ifndef S4B_SWEEP_TU
-#include "dev_lag.inc"
 
 // ------------------------------------------------------------------------------------------------
 // k_apply: R_i += mu_old[leaf] - mu_new[leaf'], relabel observations under the accepted move's root
@@ -1842,9 +1841,6 @@ class DevHip {
   ~DevHip() {
     if (graphExec_) (void)hipGraphExecDestroy(graphExec_);
     if (graph_) (void)hipGraphDestroy(graph_);
-    if (lagExec_) (void)hipGraphExecDestroy(lagExec_);
-    if (lagGraph_) (void)hipGraphDestroy(lagGraph_);
-    if (pinnedLag_) (void)hipHostFree(pinnedLag_);
     if (sweepStatus_) (void)hipHostFree(sweepStatus_);
     for (void* p : allocs_) (void)hipFree(p);
     if (pinned_) (void)hipHostFree(pinned_);
@@ -1957,22 +1953,13 @@ class DevHip {
       if (const char* g = getenv("S4B_GRIDF")) { int v = atoi(g); if (v >= 2 && v <= F_GRID_MAX) a.gridF = v; }
       const int64_t passThreads = (int64_t)(a.gridF - 1) * F_PT;
       const int64_t perThread = (nQuads + passThreads - 1) / passThreads;
-      a.candStride = (int64_t)cand_bytes(nc_); a.candBase = zalloc<unsigned char>((size_t)6 * cand_bytes(nc_));   // k_step: 2 parities x 2 images; k_lag: 3 slots x 2
+      a.candStride = (int64_t)cand_bytes(nc_); a.candBase = zalloc<unsigned char>((size_t)4 * cand_bytes(nc_));   // k_step: 2 parities x 2 images
       ldsStep_ = step_lds_bytes(nc_, d.weights != nullptr);
       // automatic choice: the fused launch wins while a tree update is latency-bound; at large n the two-kernel path keeps
       // more waves streaming (4 per SIMD instead of 2)
       fusedOk_ = perThread <= 255 && ldsStep_ + 24 * 1024 <= 160 * 1024;
       fusedAuto_ = perThread <= 8 && fusedOk_;
       a.partF = zalloc<double>((size_t)2 * 3 * a.binCap * a.gridF);
-      // lagged path (dev_lag.inc): the same grid; one control workgroup + pass workgroups that never wait for a decision
-      ldsLag_ = lag_lds_bytes(nc_);
-      lagOk_ = d.weights == nullptr && ldsLag_ + 40 * 1024 <= 160 * 1024 && a.gridF <= F_GRID_MAX;
-      if (lagOk_) {
-        lag_.desc = zalloc<int32_t>((size_t)2 * LD_WORDS); lag_.apply = zalloc<LagApply>(2); lag_.gtab = zalloc<uint32_t>((size_t)2 * LAG_COPIES * LAG_TAB * LAG_PAD);
-        lag_.cells = zalloc<uint8_t>((size_t)3 * a.npad); lag_.stat = zalloc<int32_t>(LS_WORDS);
-        HIP_OK(hipHostMalloc(&pinnedLag_, sizeof(int32_t) * 16, hipHostMallocDefault));
-        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLag_));
-      }
       // persistent sweep (dev_sweep.inc): ONE launch per sweep, the residual in registers, every workgroup deciding redundantly.
       // Needs every quad of a pass thread in registers (SW_PF of them, 5 pass waves per workgroup), all gridF workgroups resident at once (one per CU: they wait for
       // each other inside the launch) and no weights.
@@ -2190,10 +2177,6 @@ class DevHip {
       for (int k = 0; k < thin; ++k) { sweep_persistent_one(); if (binary_) launch_latents(); }
       return;
     }
-    if (path_ == PATH_LAG) {
-      for (int k = 0; k < thin; ++k) { sweep_lag_one(); if (binary_) launch_latents(); }
-      return;
-    }
     if (useGraph_) {
       if (!graphExec_ || graphTrace_ != a_.traceOn) capture_sweep();
       for (int k = 0; k < thin; ++k) {
@@ -2335,70 +2318,20 @@ class DevHip {
     out[6] = ms * 1000.0 / nSweeps;
   }
   bool fused() const { return useFused_; }
-  // ---- lagged path (dev_lag.inc): k_lag_pre + T + 2 launches when every speculated proposal image holds, one more per repair.  The
-  // sweep is replayed from a hipGraph with `lagPlanned_` launches (the trailing ones exit at once); the control workgroup raises
-  // stat[LS_DONE] when the last tree has been folded in, the host tops the sweep up in the rare case the slack was not enough.
-  void launch_lag(int j) { hipLaunchKernelGGL(k_lag, dim3(a_.gridF), dim3(LBLOCK), ldsLag_, stream_, a_, lag_, j); }
-  void capture_lag(int launches) {
-    if (lagExec_) { (void)hipGraphExecDestroy(lagExec_); lagExec_ = nullptr; }
-    if (lagGraph_) { (void)hipGraphDestroy(lagGraph_); lagGraph_ = nullptr; }
-    HIP_OK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-    hipLaunchKernelGGL(k_lag_pre, dim3(1), dim3(LBLOCK), 0, stream_, a_, lag_);
-    for (int j = 0; j < launches; ++j) launch_lag(j);
-    HIP_OK(hipMemcpyAsync(pinnedLag_, lag_.stat, sizeof(int32_t) * LS_WORDS, hipMemcpyDeviceToHost, stream_));
-    HIP_OK(hipStreamEndCapture(stream_, &lagGraph_));
-    HIP_OK(hipGraphInstantiate(&lagExec_, lagGraph_, nullptr, nullptr, 0));
-    lagCaptured_ = launches; lagTrace_ = a_.traceOn;
-  }
-  void sweep_lag_one() {
-    const int minLaunches = T_ + 2;
-    // slack: a running estimate of the repairs per sweep plus a margin, in steps of 8 launches (a re-capture costs a millisecond)
-    int want = minLaunches + (int)(lagRepairs_ + 3.0 * std::sqrt(lagRepairs_ + 1.0)) + 2;
-    want = (want + 7) / 8 * 8;
-    int launched;
-    if (useGraph_) {
-      if (!lagExec_ || lagTrace_ != a_.traceOn || want > lagCaptured_ || want + 16 < lagCaptured_) capture_lag(want);
-      HIP_OK(hipGraphLaunch(lagExec_, stream_));
-      launched = lagCaptured_;
-    } else {
-      hipLaunchKernelGGL(k_lag_pre, dim3(1), dim3(LBLOCK), 0, stream_, a_, lag_);
-      for (int j = 0; j < want; ++j) launch_lag(j);
-      HIP_OK(hipMemcpyAsync(pinnedLag_, lag_.stat, sizeof(int32_t) * LS_WORDS, hipMemcpyDeviceToHost, stream_));
-      launched = want;
-    }
-    launches_ += launched + 1;
-    sync();
-    int guard = 0;
-    while (!pinnedLag_[LS_DONE]) {
-      for (int k = 0; k < 8; ++k) launch_lag(launched++);
-      launches_ += 8; ++lagTopUps_;
-      HIP_OK(hipMemcpyAsync(pinnedLag_, lag_.stat, sizeof(int32_t) * LS_WORDS, hipMemcpyDeviceToHost, stream_));
-      sync();
-      if (++guard > 4 * T_ + 64) throw std::runtime_error("lagged tree update: the sweep does not terminate");
-    }
-    const int used = pinnedLag_[LS_LAUNCHES];
-    lagRepairs_ += 0.1 * ((double)(used - minLaunches) - lagRepairs_);
-    lagLaunchesUsed_ += used; lagBubbles_ += pinnedLag_[LS_BUBBLES]; lagSlow_ += pinnedLag_[LS_SLOW]; lagSeq_ += pinnedLag_[LS_SEQ]; ++lagSweeps_;
-  }
-  // tree-update path: 0 automatic, 1 two kernels per tree (k_tree + k_control), 2 fused (k_step), 3 lagged (k_lag)
+  // tree-update path: 0 automatic, 1 two kernels per tree (k_tree + k_control), 2 fused (k_step), 4 persistent (k_sweep); 3 was the
+  // lagged launch (k_lag) of round 3, removed: the persistent sweep does what it was after without its repair launches
   void set_tree_path(int path) {
-    if (path < 0 || path > 4) throw std::invalid_argument("tree path must be 0 (automatic), 1 (two-kernel), 2 (fused), 3 (lagged) or 4 (persistent)");
+    if (path < 0 || path > 4 || path == 3) throw std::invalid_argument("tree path must be 0 (automatic), 1 (two-kernel), 2 (fused) or 4 (persistent)");
     pathReq_ = path; choose_path();
   }
   void get_tree_path(int32_t out[2]) const { out[0] = pathReq_; out[1] = path_; }
-  void lag_stats(double out[6]) const {
-    out[0] = (double)lagSweeps_; out[1] = lagSweeps_ ? (double)lagLaunchesUsed_ / lagSweeps_ : 0.0; out[2] = lagSweeps_ ? (double)lagBubbles_ / lagSweeps_ : 0.0;
-    out[3] = (double)lagSlow_; out[4] = (double)lagSeq_; out[5] = (double)lagTopUps_;
-  }
   void choose_path() {
     int want = pathReq_;
     // automatic: the fused launch while a tree update is latency-bound (few quads per thread), two kernels per tree beyond and when
-    // three or more chains share the device.  The lagged path is never chosen automatically: measured on MI355X it does not beat
-    // them (every fifth to tenth launch is a repair, and the pass of a 254-VGPR kernel is latency-bound)
+    // three or more chains share the device.
     // The persistent sweep wherever it applies and the chain has the device to itself (its workgroups wait for each other).
     if (want == 0) want = sharing_ >= 3 ? PATH_TWO : ((sweepOk_ && sharing_ <= 1) ? PATH_SWEEP : (fusedAuto_ ? PATH_FUSED : PATH_TWO));
     if (want == PATH_SWEEP && !sweepOk_) want = fusedOk_ ? PATH_FUSED : PATH_TWO;
-    if (want == PATH_LAG && !lagOk_) want = fusedOk_ ? PATH_FUSED : PATH_TWO;
     if (want == PATH_FUSED && !fusedOk_) want = PATH_TWO;
     if (want == path_) return;
     path_ = want; useFused_ = path_ == PATH_FUSED;
@@ -2409,70 +2342,6 @@ class DevHip {
   // higher aggregate rate (measured at n = 1e6: 4 chains 512 vs 425 iterations/s; 2 chains 379 vs 403).  Between sweeps both
   // paths start from the same state (main tree arrays, generator slot 0), so the switch is safe at any call boundary.
   void set_device_sharing(int chains) { sharing_ = chains; choose_path(); }
-  // lagged path: HIP events around every launch of extra sweeps; the average is over launches that did all three things (fold a
-  // tree in, gather statistics, decide beside them), out[3] counts them; out[1] = launches used per sweep, out[2] = repairs per sweep
-  void profile_sweep_lag(int nSweeps, int thin, double* out) {
-    const int cap = 2 * T_ + 64;
-    std::vector<hipEvent_t> ev((size_t)cap + 1);
-    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
-    double sum = 0, cnt = 0, used = 0, bub = 0;
-    for (int sIdx = 0; sIdx < nSweeps * thin; ++sIdx) {
-      hipLaunchKernelGGL(k_lag_pre, dim3(1), dim3(LBLOCK), 0, stream_, a_, lag_); ++launches_;
-      int launched = 0;
-      for (;;) {
-        const int from = launched;
-        HIP_OK(hipEventRecord(ev[0], stream_));
-        for (int k = 0; k < cap && (launched < T_ + 2 || k < 8); ++k) { launch_lag(launched++); ++launches_; HIP_OK(hipEventRecord(ev[(size_t)k + 1], stream_)); }
-        HIP_OK(hipMemcpyAsync(pinnedLag_, lag_.stat, sizeof(int32_t) * LS_WORDS, hipMemcpyDeviceToHost, stream_));
-        sync();
-        const int nUsed = pinnedLag_[LS_LAUNCHES];
-        // launches 2 .. used - 3 of an undisturbed sweep are steady; with repairs in between the average includes them (they are
-        // part of what a tree update costs)
-        for (int k = from; k < launched && k < nUsed; ++k) {
-          if (k < 2 || k >= nUsed - 2) continue;
-          float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[(size_t)(k - from)], ev[(size_t)(k - from) + 1]));
-          sum += ms * 1000.0; cnt += 1;
-        }
-        if (pinnedLag_[LS_DONE]) break;
-        if (launched > 8 * T_ + 64) throw std::runtime_error("lagged tree update: the sweep does not terminate");
-      }
-      used += pinnedLag_[LS_LAUNCHES]; bub += pinnedLag_[LS_BUBBLES];
-      if (binary_) launch_latents();
-    }
-    sync();
-    for (auto& e : ev) (void)hipEventDestroy(e);
-#ifdef S4B_LAG_TIMING
-    { unsigned long long h[32]; HIP_OK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lag), sizeof(h)));
-      const double kp = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0, kc = h[8] ? 1.0 / (100.0 * (double)h[8]) : 0.0;
-      fprintf(stderr, "LAGT pass workgroup 100, us from its start (avg over %llu launches): descriptor %.2f, tables staged %.2f, quads done %.2f, sums reduced %.2f, end %.2f\n",
-              h[0], h[1] * kp, h[2] * kp, (double)(h[3] - h[6]) * kp, (double)(h[4] - h[6]) * kp, (double)(h[5] - h[6]) * kp);
-      fprintf(stderr, "LAGT pass, first group of the timed thread (us from workgroup start): data here %.2f, folded + stored %.2f, first level %.2f, routed %.2f, table + sums %.2f\n",
-              (double)(h[16] - h[6]) * kp, (double)(h[17] - h[6]) * kp, (double)(h[18] - h[6]) * kp, (double)(h[19] - h[6]) * kp, (double)(h[20] - h[6]) * kp);
-      fprintf(stderr, "LAGT control workgroup, us from its start (avg over %llu launches): reducers done %.2f, wave 0 has the totals %.2f, decided %.2f, wave 0 at the barrier %.2f, images drawn %.2f, barrier passed %.2f, end %.2f\n",
-              h[8], h[9] * kc, h[10] * kc, h[11] * kc, h[12] * kc, h[13] * kc, h[14] * kc, h[15] * kc);
-      { static unsigned long long ws[256], we[256];
-        HIP_OK(hipMemcpyFromSymbol(ws, HIP_SYMBOL(g_lagS), sizeof(ws))); HIP_OK(hipMemcpyFromSymbol(we, HIP_SYMBOL(g_lagE), sizeof(we)));
-        const int G = a_.gridF; unsigned long long s0 = ~0ull; for (int b = 0; b < G; ++b) if (ws[b] && ws[b] < s0) s0 = ws[b];
-        const double k = h[8] ? 1.0 / (100.0 * (double)h[8]) : 0.0;
-        double lastStart = 0, lastEnd = 0, firstEnd = 1e30; int bS = 0, bE = 0;
-        for (int b = 0; b < G; ++b) { const double st = (double)(ws[b] - s0) * k, en = (double)(we[b] - s0) * k; if (st > lastStart) { lastStart = st; bS = b; } if (en > lastEnd) { lastEnd = en; bE = b; } if (en < firstEnd) firstEnd = en; }
-        fprintf(stderr, "LAGT workgroups (avg us after the earliest start): last start %.2f (block %d), first end %.2f, last end %.2f (block %d); control workgroup start %.2f end %.2f; blocks 0, 100, 200 start %.2f %.2f %.2f end %.2f %.2f %.2f\n",
-                lastStart, bS, firstEnd, lastEnd, bE, (double)(ws[G - 1] - s0) * k, (double)(we[G - 1] - s0) * k,
-                (double)(ws[0] - s0) * k, (double)(ws[100] - s0) * k, (double)(ws[200] - s0) * k, (double)(we[0] - s0) * k, (double)(we[100] - s0) * k, (double)(we[200] - s0) * k);
-        memset(ws, 0, sizeof(ws)); HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_lagS), ws, sizeof(ws))); HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_lagE), ws, sizeof(ws))); }
-      unsigned long long z[32] = {0}; HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_lag), z, sizeof(z))); }
-#endif
-    const double ns = (double)nSweeps * thin;
-    out[0] = cnt ? sum / cnt : 0.0; out[3] = cnt;
-    out[1] = used / ns; out[4] = 0.0;
-    out[2] = bub / ns; out[5] = 0.0;
-    HIP_OK(hipEventRecord(evStart_, stream_));
-    for (int sIdx = 0; sIdx < nSweeps; ++sIdx) sweep(thin);
-    HIP_OK(hipEventRecord(evStop_, stream_));
-    sync();
-    float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_));
-    out[6] = ms * 1000.0 / nSweeps;
-  }
   // persistent path: the sweep IS one launch; out[0] = its average duration (HIP events on the sampler's stream), out[1] = sweeps that
   // were handed over to k_step so far / all persistent sweeps so far (out[4]), out[6] = wall time per sweep without events
   void profile_sweep_persistent(int nSweeps, int thin, double* out) {
@@ -2517,7 +2386,6 @@ class DevHip {
   }
   void profile_sweep(int nSweeps, int thin, double* out) {
     if (path_ == PATH_SWEEP) { profile_sweep_persistent(nSweeps, thin, out); return; }
-    if (path_ == PATH_LAG) { profile_sweep_lag(nSweeps, thin, out); return; }
     if (useFused_) { profile_sweep_fused(nSweeps, thin, out); return; }
     const int perSweep = 2 * T_ * thin + thin;
     std::vector<hipEvent_t> ev((size_t)perSweep * 2 + 4);
@@ -2717,6 +2585,7 @@ class DevHip {
     fxLastBad_ = fusedEvals_;
   }
   void fused_stats(int64_t out[2]) const { out[0] = fusedEvals_; out[1] = fusedFallbacks_; }
+  void sweep_stats(int64_t out[2]) const { out[0] = sweepCount_; out[1] = sweepHandOvers_; }
 
   // HIP-event timing of the per-leapfrog O(N) sums (hmc_mode 1 path: e = e0 - X beta - Z b, |e|^2, X'e, Z'e) on the
   // sampler's stream.  out: [0] us per evaluation, kernels only; [1] us per evaluation including the result fetch;
@@ -2815,13 +2684,11 @@ class DevHip {
 
   int device_ = 0; hipStream_t stream_ = nullptr; hipEvent_t evStart_ = nullptr, evStop_ = nullptr;
   int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1; bool binary_ = false;
-  size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0, ldsLag_ = 0; bool useFused_ = false, fusedAuto_ = false, fusedOk_ = false, lagOk_ = false;
-  enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_LAG = 3, PATH_SWEEP = 4 };
+  size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0; bool useFused_ = false, fusedAuto_ = false, fusedOk_ = false;
+  enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_SWEEP = 4 };
   bool sweepOk_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
   int64_t sweepCount_ = 0, sweepHandOvers_ = 0;
   int pathReq_ = 0, path_ = 0, sharing_ = 1;
-  LagArrays lag_{}; int32_t* pinnedLag_ = nullptr; hipGraph_t lagGraph_ = nullptr; hipGraphExec_t lagExec_ = nullptr; int lagCaptured_ = 0, lagTrace_ = -1;
-  double lagRepairs_ = 4.0; int64_t lagLaunchesUsed_ = 0, lagBubbles_ = 0, lagSlow_ = 0, lagSeq_ = 0, lagSweeps_ = 0, lagTopUps_ = 0;
   double dbgSweepMs_ = 0; int dbgSweeps_ = 0;
   hipGraph_t graph_ = nullptr; hipGraphExec_t graphExec_ = nullptr; int graphTrace_ = -1; bool useGraph_ = true;
   BartArrays a_; StanArrays s_;

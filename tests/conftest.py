@@ -267,7 +267,7 @@ def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True, sharing
         out["pm"] = s.get_parametric_mean()
         out["counters"] = s.get_counters()
         out["tree_path"] = s.get_tree_path()
-        out["lag_stats"] = s.get_lag_stats()
+        out["sweep_stats"] = s.get_sweep_stats()
         out["fused_stats"] = s.get_fused_stats()
     finally:
         s.free()

@@ -11,7 +11,7 @@ import pytest
 from conftest import assert_chain_parity, run_chain
 
 pytestmark = pytest.mark.gpu
-PATHS = ["fused", "two-kernel", "lagged"]
+PATHS = ["persistent", "fused", "two-kernel"]
 
 
 def random_case(seed):
@@ -81,8 +81,8 @@ def test_random_configuration(oracle_lib, hip_lib, seed, path):
     a = run_chain(oracle_lib, "orc_", args, results_type=rt)
     # (the oracle takes no hmc_mode: both modes must reproduce it)
     b = run_chain(hip_lib, "s4b_", args, results_type=rt, tree_path=path)
-    # (the lagged launch has no weighted instantiation and a smaller LDS budget for the node tables: there the sampler reports
-    # the path it took instead — s4b_get_tree_path returns both)
+    # (the persistent sweep has no weighted instantiation and needs the fused launch's LDS budget for its hand-over: there the sampler
+    # reports the path it took instead — s4b_get_tree_path returns both)
     assert b["tree_path"][0] == path and (b["tree_path"][1] == path or what["weights"] or what["capacity"]), (what, b["tree_path"])
     try:
         assert_chain_parity(a, b, stan=joint)

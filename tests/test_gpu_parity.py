@@ -39,36 +39,49 @@ def test_hip_matches_oracle(oracle_lib, hip_lib, kw):
 
 
 @pytest.mark.parametrize("n", [5000, 1003])
-@pytest.mark.parametrize("path", ["fused", "two-kernel", "lagged"])
+@pytest.mark.parametrize("path", ["persistent", "fused", "two-kernel"])
 def test_bart_block_long_run(oracle_lib, hip_lib, n, path):
-    """2400 tree updates on each of the three tree-update paths of the device layer (s4b_set_tree_path): one fused launch per tree
-    (k_step), two kernels per tree (k_tree + k_control), and the lagged launch (k_lag: pass and decision side by side, integer
-    contingency table, repair launches when a speculated proposal image does not hold)."""
+    """2400 tree updates on each of the three tree-update paths of the device layer (s4b_set_tree_path): the persistent sweep
+    (k_sweep: one launch per sweep, residual in registers, bin partials exchanged through integer atomics), one fused launch per
+    tree (k_step), two kernels per tree (k_tree + k_control)."""
     args, _ = friedman_case(n=n, T=40, warmup=30, iter=60)
     a = run_chain(oracle_lib, "orc_", args, results_type=1)
     b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path=path)
     assert b["tree_path"] == (path, path)
     assert len(a["trace"]) == 40 * 60 and set(np.unique(a["trace"][:, 0])) == {0, 1, 2, 3}
     assert_chain_parity(a, b, stan=False)
-    if path == "lagged":
-        st = b["lag_stats"]
-        # every accepted birth / death costs one repair launch; a sweep is T + 2 launches plus the repairs
-        assert st["sweeps"] == 60 and st["repairs_per_sweep"] > 0
-        assert abs(st["launches_per_sweep"] - (40 + 2 + st["repairs_per_sweep"])) < 1e-9 and st["slow_passes"] == 0
+    if path == "persistent":
+        assert b["sweep_stats"] == (60, 0)        # every sweep of the run in one launch, none handed over
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(n=1003, T=50), dict(n=7, T=3, warmup=2, iter=4, ranef=False), dict(T=1, warmup=10, iter=30, ranef=False),
                                 dict(T=2, warmup=10, iter=30), dict(n_test=17), dict(slopes=True)], ids=str)
-def test_lagged_path_joint_chain(oracle_lib, hip_lib, kw):
-    """the joint (Stan + BART) chain on the lagged tree update: the same draws as the oracle"""
+def test_fused_path_joint_chain(oracle_lib, hip_lib, kw):
+    """the joint (Stan + BART) chain on the fused tree update (the automatic choice is the persistent sweep: test_hip_matches_oracle
+    covers that one): the same draws as the oracle"""
     args = friedman_case(**kw)[0]
     a = run_chain(oracle_lib, "orc_", args)
-    b = run_chain(hip_lib, "s4b_", args, tree_path="lagged")
-    assert b["tree_path"][1] == "lagged"
+    b = run_chain(hip_lib, "s4b_", args, tree_path="fused")
+    assert b["tree_path"][1] == "fused"
     assert_chain_parity(a, b)
 
 
-@pytest.mark.parametrize("paths", [("lagged", "fused"), ("two-kernel", "lagged"), ("fused", "lagged")], ids=str)
+def test_automatic_path_is_the_persistent_sweep(hip_lib):
+    """no weights, the chain alone on the device, at most 16 observations per pass thread: k_sweep; with weights: the fused launch;
+    three chains on the device: two kernels per tree"""
+    from conftest import make_sampler
+    for kw, sharing, want in ((dict(), None, "persistent"), (dict(weights=np.random.default_rng(1).random(3000) + 0.5), None, "fused"), (dict(), 3, "two-kernel")):
+        args, _ = friedman_case(n=3000, T=5, warmup=2, iter=4, **kw)
+        s = make_sampler(hip_lib, "s4b_", args)
+        try:
+            if sharing:
+                s.set_device_sharing(sharing)
+            assert s.get_tree_path() == ("auto", want)
+        finally:
+            s.free()
+
+
+@pytest.mark.parametrize("paths", [("persistent", "fused"), ("two-kernel", "persistent"), ("fused", "persistent")], ids=str)
 def test_tree_path_can_change_between_runs(oracle_lib, hip_lib, paths):
     """every path starts a sweep from the same state (main tree arrays, residual, generator slot 0): switching between warm-up and
     sampling gives the oracle's chain"""
@@ -113,16 +126,17 @@ def test_user_offset_types(oracle_lib, hip_lib):
         assert_chain_parity(run_chain(oracle_lib, "orc_", args), run_chain(hip_lib, "s4b_", args))
 
 
-@pytest.mark.parametrize("path", [None, "lagged"])
+@pytest.mark.parametrize("path", ["persistent", "fused", "two-kernel"])
 def test_multi_pass_bins_and_deep_trees(oracle_lib, hip_lib, path):
-    """> 16 leaves: several bin passes (k_step / k_tree); on the lagged path the slow (one step at a time) passes and decisions"""
+    """> 16 leaves: several bin passes (8 bins per pass in k_sweep, 16 in k_step / k_tree); trees that outgrow the 64 node slots of
+    the wave-register control path: k_sweep hands the rest of such a sweep over to k_step launches"""
     args, _ = friedman_case(n=2000, T=4, warmup=20, iter=40, ranef=False, bart_args={"base": 0.99, "power": 0.45, "k": 0.5})
     a = run_chain(oracle_lib, "orc_", args, results_type=1)
     b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path=path)
     assert a["trace"][:, 4].max() > 16
     assert_chain_parity(a, b, stan=False)
-    if path == "lagged":
-        assert b["lag_stats"]["slow_passes"] > 0 and b["lag_stats"]["decisions_alone"] > 0
+    if path == "persistent":
+        assert b["tree_path"][1] == "persistent" and b["sweep_stats"][0] == 40
 
 
 def test_large_node_capacity_global_fallback(oracle_lib, hip_lib):
@@ -202,10 +216,11 @@ def test_probit_matches_oracle(oracle_lib, hip_lib, kw):
     assert np.all(a["sample"]["bart"]["sigma"] == 1.0) and "aux.1" not in b["names"]
 
 
-@pytest.mark.parametrize("path", ["lagged", "two-kernel"])
+@pytest.mark.parametrize("path", ["fused", "two-kernel"])
 def test_probit_and_thinning_on_the_other_tree_paths(oracle_lib, hip_lib, path):
     """binary response (latents drawn between sweeps from the same generator the sweep leaves in slot 0) and skip = (2, 1): two BART
-    sweeps per Gibbs iteration, on the lagged and on the two-kernel tree update"""
+    sweeps per Gibbs iteration, on the fused and on the two-kernel tree update (the automatic choice — the persistent sweep — is
+    covered by test_probit_matches_oracle and test_hip_matches_oracle)"""
     for args in (_binary_case(n=747, T=20, n_test=11), friedman_case(n=1200, T=9, skip=(2, 1), warmup=5, iter=10)[0]):
         a = run_chain(oracle_lib, "orc_", args)
         b = run_chain(hip_lib, "s4b_", args, tree_path=path)
@@ -220,9 +235,11 @@ def test_trees_with_more_than_128_node_slots(oracle_lib, hip_lib):
     args.node_capacity = 1024
     a = run_chain(oracle_lib, "orc_", args, results_type=1)
     assert a["trace"][:, 4].max() > 128
-    for path in (None, "lagged"):     # (lagged: the steps beyond the wave-register path run on the global arrays inside k_lag)
+    for path in ("persistent", "fused"):     # (persistent: sweeps are handed over to k_step launches where a tree outgrows the wave path)
         b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path=path)
         assert_chain_parity(a, b, stan=False)
+        if path == "persistent" and b["tree_path"][1] == "persistent":
+            assert b["sweep_stats"][1] > 0
 
 
 @pytest.mark.parametrize("sharing", [(4, None), (None, 4), (4, 1)])

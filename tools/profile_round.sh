@@ -7,7 +7,7 @@
 #      profiles/pmc_traffic.json (HBM bytes per launch of the tree-update kernel: k_step at n = 1e6, k_tree<true> at n = 1e7; gfx950 correction of MI355X_MICROARCH.md)
 # Counter passes are separate runs without any tracing option, and the program after `--` is python3 itself.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT" "$ROOT/profiles"
@@ -27,9 +27,9 @@ for N in 1000000 10000000; do
   TRAFFIC="$TRAFFIC, \"$N\": $(python3 "$ROOT/tools/pmc_traffic.py" "$F" "$W" $N)"
 done
 echo "$TRAFFIC}" > "$ROOT/profiles/pmc_traffic.json"
-# the lagged tree update (k_lag), opt-in path: per-kernel durations at the metric's workload
-rm -rf "$OUT/prof_lagged"
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_lagged" -- python3 "$ROOT/bench.py" --n 1000000 --no-cpu-baseline --no-extra-configs --target-n 0 --burn-in 30 --steps 5 --warmup 1 --tree-path lagged > "$OUT/bench_prof_lagged.log" 2>&1
-python3 "$ROOT/tools/rocpd_summary.py" "$(newest_db "$OUT/prof_lagged")" "$ROOT/profiles/${TAG}_rocprofv3_prof_lagged_n1000000.txt"
+# the fused launch per tree (k_step: the automatic choice of rounds 2-3, now the hand-over target of the persistent sweep): per-kernel durations
+rm -rf "$OUT/prof_fused"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_fused" -- python3 "$ROOT/bench.py" --n 1000000 --no-cpu-baseline --no-extra-configs --target-n 0 --burn-in 30 --steps 5 --warmup 1 --tree-path fused > "$OUT/bench_prof_fused.log" 2>&1
+python3 "$ROOT/tools/rocpd_summary.py" "$(newest_db "$OUT/prof_fused")" "$ROOT/profiles/${TAG}_rocprofv3_prof_fused_n1000000.txt"
 # the box's repository copy is scratch: hand the summaries back through gpurun_out/
 mkdir -p "$OUT/profiles" && cp "$ROOT"/profiles/${TAG}_rocprofv3_* "$ROOT/profiles/pmc_traffic.json" "$OUT/profiles/"

@@ -9,7 +9,7 @@ t0 = time.time()
 # 1. long BART-only parity run (speculation must never change the stream)
 args, _ = friedman_case(n=20000, T=50, warmup=150, iter=300)
 a = run_chain(orc, "orc_", args, results_type=1)
-for path in ("fused", "two-kernel", "lagged"):
+for path in ("persistent", "fused", "two-kernel"):
     b = run_chain(hip, "s4b_", args, results_type=1, tree_path=path)
     assert b["tree_path"][1] == path
     assert_chain_parity(a, b, stan=False)
