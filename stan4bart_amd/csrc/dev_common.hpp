@@ -16,7 +16,10 @@ struct ScaleState {
   double sigma;                // sigmaData / range
 };
 
-enum : int32_t { S4B_ERR_NODE_CAPACITY = 1, S4B_ERR_TRACE_OVERFLOW = 2, S4B_ERR_INTERNAL = 4 };
+enum : int32_t { S4B_ERR_NODE_CAPACITY = 1, S4B_ERR_TRACE_OVERFLOW = 2, S4B_ERR_INTERNAL = 4,
+                 // which internal check (diagnostics; always together with S4B_ERR_INTERNAL): a bin partial outside the fixed-point range of the
+                 // exchange words, a control step that does not fit the wave path, a wait that never ended, an exchange that never completed
+                 S4B_ERR_I_RANGE = 256, S4B_ERR_I_FITS = 512, S4B_ERR_I_WAIT = 1024, S4B_ERR_I_GATHER = 2048 };
 
 // header of one scratch set: the pending proposal of the set's tree and (fused path) the scalars of the tree's snapshot
 struct StepHeader { Proposal pr; int32_t hwm, nl, ni, g, gn, valid; double logPi; };

@@ -798,7 +798,7 @@ class SamplerCore {
   void check_device() {
     int32_t e = dev_.error_flags();
     if (e & S4B_ERR_NODE_CAPACITY) throw std::runtime_error("a tree outgrew node_capacity; re-create the sampler with a larger bart_control.node_capacity");
-    if (e & S4B_ERR_INTERNAL) throw std::runtime_error("internal error: a hand-shake of the control kernel timed out");
+    if (e & S4B_ERR_INTERNAL) throw std::runtime_error("internal error: a hand-shake of the control kernel timed out (device error word " + std::to_string(e) + ")");
     if (e & S4B_ERR_TRACE_OVERFLOW) throw std::runtime_error("trace buffer overflow: call get_trace more often");
   }
 

@@ -51,7 +51,7 @@ def test_bart_block_long_run(oracle_lib, hip_lib, n, path):
     assert len(a["trace"]) == 40 * 60 and set(np.unique(a["trace"][:, 0])) == {0, 1, 2, 3}
     assert_chain_parity(a, b, stan=False)
     if path == "persistent":
-        assert b["sweep_stats"] == (60, 0)        # every sweep of the run in one launch, none handed over
+        assert b["sweep_stats"] == (61, 0)        # the sweep at creation + every sweep of the run, each in one launch, none handed over
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(n=1003, T=50), dict(n=7, T=3, warmup=2, iter=4, ranef=False), dict(T=1, warmup=10, iter=30, ranef=False),
@@ -136,7 +136,7 @@ def test_multi_pass_bins_and_deep_trees(oracle_lib, hip_lib, path):
     assert a["trace"][:, 4].max() > 16
     assert_chain_parity(a, b, stan=False)
     if path == "persistent":
-        assert b["tree_path"][1] == "persistent" and b["sweep_stats"][0] == 40
+        assert b["tree_path"][1] == "persistent" and b["sweep_stats"][0] == 41
 
 
 def test_large_node_capacity_global_fallback(oracle_lib, hip_lib):
