@@ -1961,7 +1961,7 @@ class DevHip {
       fusedAuto_ = perThread <= 8 && fusedOk_;
       a.partF = zalloc<double>((size_t)2 * 3 * a.binCap * a.gridF);
       // persistent sweep (dev_sweep.inc): ONE launch per sweep, the residual in registers, every workgroup deciding redundantly.
-      // Needs every quad of a pass thread in registers (SW_PF of them, 5 pass waves per workgroup), all gridF workgroups resident at once (one per CU: they wait for
+      // Needs every quad of a pass thread in registers (SW_PF of them, 4 pass waves per workgroup), all gridF workgroups resident at once (one per CU: they wait for
       // each other inside the launch) and no weights.
       {
         hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, device_));
@@ -2372,7 +2372,7 @@ class DevHip {
       const double k = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0;
       fprintf(stderr, "SWEEP workgroup 100 (avg over %llu steps, %.2f bins, %llu routed after the decision) | pass waves, us after the previous publish: totals gathered (wave 3) %.2f; wave 4: images there %.2f, routed %.2f, tables + proposal there %.2f, arithmetic done %.2f; published (wave 3) = step %.2f | decider, us after its previous step: totals seen %.2f, verdict %.2f, tables out %.2f, step end %.2f | image wave 1, us after its previous image: starts drawing %.2f, drawn %.2f\n",
               h[0], h[0] ? (double)h[7] / (double)h[0] : 0.0, h[8], h[1] * k, h[2] * k, h[3] * k, h[4] * k, h[5] * k, h[6] * k, h[9] * k, h[10] * k, h[11] * k, h[12] * k, h[13] * k, h[14] * k);
-      fprintf(stderr, "SWEEP arithmetic done, us after the wave's own previous pass: waves 3..7: %.2f %.2f %.2f %.2f %.2f\n", h[16] * k, h[17] * k, h[18] * k, h[19] * k, h[20] * k);
+      fprintf(stderr, "SWEEP folded in, us after the wave's own previous pass: waves 4..7: %.2f %.2f %.2f %.2f\n", h[16] * k, h[17] * k, h[18] * k, h[19] * k);
       fprintf(stderr, "SWEEP wave 5 (no side jobs), us after its previous pass: images there %.2f, routed %.2f, tables + proposal there %.2f, folded in %.2f, reduced (+ wave 3 published) %.2f\n", h[24] * k, h[25] * k, h[26] * k, h[27] * k, h[28] * k);
       fprintf(stderr, "SWEEP statistics phase: wave 5 accumulated %.2f, wave-reduced + slots written %.2f, barrier passed %.2f; wave 3 barrier passed %.2f\n", h[30] * k, h[31] * k, h[32] * k, h[33] * k); }
 #endif

@@ -796,12 +796,12 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
   const int nl = ca.nl;
   leaf_stats_draws(tb, ca, binCnt, binSum, binWt, acc != 0, deathAcc, nd, cDeath, sDeath, wDeath, wk, rng);
   S4B_DEC_T(5);
+  *accepted = acc;     // (known to the hook: the device path hands the accept flag and the old leaf values on before the leaf arithmetic)
   drawsDone();
   leaves_draw(wk.lc, wk.ls, wk.lw, wk.u1, wk.u2, nl, sigma2, m.leafPrec, wk.val);
   S4B_DEC_T(6);
   for (int i = 0; i < nl; ++i) { int n = ca.leaf.get(i); cnt.set(n, (int32_t)wk.lc.get(i)); mu.set(n, wk.val.get(i)); }
   if (rec) { rec->type = prType; rec->status = prStatus == 1 ? acc : -1; rec->var = pr->var; rec->split = pr->split; rec->numLeaves = nl; }
-  *accepted = acc;
   S4B_DEC_T(7);
   return hwm;
 }
