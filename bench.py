@@ -105,7 +105,7 @@ def sweep_roofline(prof, path, n, trees):
            "avg_launch_us": prof["stats_us"], "algorithmic_bytes_per_launch": per_launch,
            "timing": "HIP events around every launch on the sampler's stream (adds ~2 us per launch; profiles/ has rocprofv3)",
            "sweep_wall_us": prof["sweep_wall_us"], "tree_update_wall_us": prof["sweep_wall_us"] / trees,
-           "achieved_GBs_whole_sweep": per_launch * trees / (prof["sweep_wall_us"] * 1e-6) / 1e9}
+           "achieved_GBs_whole_sweep": 22.0 * n * trees / (prof["sweep_wall_us"] * 1e-6) / 1e9}
     rec["achieved"] = per_launch / (prof["stats_us"] * 1e-6) / 1e9
     rec["frac"] = rec["achieved"] / HBM_PEAK_GBS
     if path == "persistent":
@@ -273,8 +273,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--no-hmc-mode1", action="store_true")
+    ap.add_argument("--mode-iters", type=int, default=100, help="iterations of the like-for-like leg that times both gradient modes from one saved state")
     ap.add_argument("--profile-sweeps", type=int, default=2)
     ap.add_argument("--tree-path", default="auto", choices=["auto", "two-kernel", "fused", "persistent"])
+    ap.add_argument("--c5-n", type=int, default=10_000_000, help="observations of the BASELINE config 5 leg of extra_configs (0 = skip; N = 1 only)")
     ap.add_argument("--target-n", type=int, default=10_000_000,
                     help="also measure the sweep kernel at north_star's roofline-target size (0 = skip; N = 1 only)")
     ap.add_argument("--emul", action="store_true",
@@ -355,21 +357,28 @@ def main():
     barrier()
     hmc_mode = sampler.get_hmc_mode()
     tree_path = sampler.get_tree_path()[1] if not a.emul else "emulation"
-    # ---- the same chain with one O(N) device evaluation per leapfrog (the reference's cost model), W untimed + K timed
+    # ---- both gradient modes over the SAME iterations: the chain is saved (s4b_get_state), `--mode-iters` sampling iterations are
+    # timed with sufficient statistics gathered once per iteration (mode 0, the headline's mode), the state is put back and the same
+    # iterations are timed again with one O(N) device evaluation per leapfrog (mode 1, the reference's cost model).  The two legs
+    # start from the same state and generator positions, so they do the same leapfrogs up to rounding.
     dt1 = None
+    modes = None
     if not a.no_hmc_mode1 and not a.emul:
-        sampler.set_hmc_mode(1)
-        if a.warmup > 0:
-            sampler.run(a.warmup, False, 0)
-        barrier()
-        m0 = sampler.get_nuts_stats()
-        t0 = time.perf_counter()
-        sampler.run(a.steps, False, 0)
-        torch.cuda.synchronize()
-        dt1 = time.perf_counter() - t0
-        m1 = sampler.get_nuts_stats()
-        barrier()
+        state0 = sampler.get_state()
+        legs = {}
+        for mode in (0, 1):
+            sampler.set_state(state0)
+            sampler.set_hmc_mode(mode)
+            barrier()
+            m0 = sampler.get_nuts_stats()
+            t0 = time.perf_counter()
+            sampler.run(a.mode_iters, False, 0)
+            torch.cuda.synchronize()
+            legs[mode] = (time.perf_counter() - t0, (sampler.get_nuts_stats()["sum_n_leapfrog"] - m0["sum_n_leapfrog"]) / a.mode_iters)
+            barrier()
         sampler.set_hmc_mode(hmc_mode)
+        dt1 = legs[1][0]
+        modes = legs
 
     def max_over_ranks(x):
         if world == 1:
@@ -435,9 +444,13 @@ def main():
             except (OSError, ValueError, KeyError):
                 pass
         if dt1_max is not None:
-            rec["per_chain_hmc_mode1"] = {"value": a.steps / dt1_max, "unit": "Gibbs iterations/s/chain", "ms_per_step": 1e3 * dt1_max / a.steps,
-                                          "n_leapfrog_per_step": (m1["sum_n_leapfrog"] - m0["sum_n_leapfrog"]) / a.steps,
-                                          "note": "same chain, continued after the headline's timed region with hmc_mode 1: every leapfrog launches k_stan_fused over all N observations"}
+            rec["gradient_modes_same_iterations"] = {
+                "iterations": a.mode_iters, "from": "one saved state (s4b_get_state / s4b_set_state), sampling phase, rank 0's chain",
+                "hmc_mode0": {"iters_per_sec": a.mode_iters / modes[0][0], "ms_per_step": 1e3 * modes[0][0] / a.mode_iters, "n_leapfrog_per_step": modes[0][1]},
+                "hmc_mode1": {"iters_per_sec": a.mode_iters / modes[1][0], "ms_per_step": 1e3 * modes[1][0] / a.mode_iters, "n_leapfrog_per_step": modes[1][1]}}
+            rec["per_chain_hmc_mode1"] = {"value": a.mode_iters / dt1_max, "unit": "Gibbs iterations/s/chain", "ms_per_step": 1e3 * dt1_max / a.mode_iters,
+                                          "n_leapfrog_per_step": modes[1][1],
+                                          "note": "hmc_mode 1 (every leapfrog launches k_stan_fused over all N observations) over the iterations of gradient_modes_same_iterations"}
         if prof is not None:
             # HBM traffic of the tree kernel: REPLAYED from the PMC passes committed under profiles/ (rocprofv3 cannot wrap this
             # process from inside; collected on this command line by tools/profile_round.sh, see profiles/pmc_traffic.json)
@@ -462,7 +475,11 @@ def main():
                                    "frac": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                    "avg_eval_us": lf["kernels_us"], "avg_eval_us_with_result_fetch": lf["with_fetch_us"],
                                    "launches_per_eval": lf["launches"], "algorithmic_bytes_per_eval": lf["algorithmic_bytes"],
-                                   "note": "N (8K + 12z + 20) bytes per leapfrog (SURVEY 8d B_lf); in the timed region of per_chain_hmc_mode1, not of the headline"}
+                                   "bytes_the_kernel_reads_per_eval": float(n) * (8 * 2 + 12 * 3 + 8),
+                                   "frac_against_bytes_read": float(n) * (8 * 2 + 12 * 3 + 8) / (lf["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                   "note": "frac: N (8K + 12z + 20) bytes per leapfrog (SURVEY 8d B_lf) / time; the DIRECT kernel reads e0 = y - offset instead of y and offset and "
+                                           "no row pointers (fixed row length): N (8K + 12z + 8) bytes really move, frac_against_bytes_read is what HBM sustains; "
+                                           "in the timed region of per_chain_hmc_mode1, not of the headline"}
         if target is not None:
             try:
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -503,6 +520,50 @@ def main():
             v2g, s2g = time_chain(lib, "s4b_", a2g, 12345, 100, 200)
             extra["config2"] = {"workload": "Friedman n=1e5, p=10, ntree=200, fixed effects only (BASELINE config 2)",
                                 "gpu_iters_per_sec": v2g, "gpu_seconds": s2g, "cpu_port_iters_per_sec": v2c, "cpu_seconds": s2c, "cpu_cores": 1}
+            # BASELINE config 4 at its shape: the 747 x 25 IHDP covariates, 26-level group with a random slope on the treatment,
+            # binary outcome / probit link (the latents are drawn on the device from R's stream), counterfactual test rows
+            from stan4bart_amd.abi import Sampler as _S
+            from stan4bart_amd.cases import c5_case, ihdp_case
+            a4 = ihdp_case(warmup=200, iter=600, T=75)
+            a4.device = local_rank
+            v4, s4 = time_chain(lib, "s4b_", a4, 12345, 200, 400)
+            extra["config4"] = {"workload": "IHDP shape: n=747, 25 covariates + treatment, ntree=75, (1+z|g1) with 26 levels, binary outcome / probit link, "
+                                            "747 counterfactual test rows (BASELINE config 4; the outcome is this repository's surrogate, DESIGN.md 7)",
+                                "gpu_iters_per_sec": v4, "gpu_seconds": s4}
+            if a.c5_n > 0:
+                # BASELINE config 5 ("HBM-roofline run"): n = 1e7, P = 100, ntree = 400, 200 groups with random slopes (q = 400, z = 2)
+                t5 = time.perf_counter()
+                a5, xb5 = c5_case(a.c5_n, warmup=4, iter=12, keep_fits=False, device=local_rank)
+                del xb5
+                r5 = RRng(777)
+                a5.seed = int(r5.sample_int(2147483647, 1)[0])
+                s5 = _S(lib, "s4b_", a5, r5.state)
+                t5c = time.perf_counter()
+                s5.run(4, True, 0)
+                s5.disengage_adaptation()
+                n0 = s5.get_nuts_stats()
+                t0 = time.perf_counter()
+                s5.run(6, False, 0)
+                torch.cuda.synchronize()
+                d5 = time.perf_counter() - t0
+                n1 = s5.get_nuts_stats()
+                path5 = s5.get_tree_path()[1]
+                p5 = s5.profile_sweep(1)
+                l5 = s5.profile_leapfrog(5)
+                s5.free()
+                rf5 = sweep_roofline(p5, path5, a.c5_n, 400)
+                K5, z5 = 2, 2
+                read5 = float(a.c5_n) * (8 * K5 + 12 * z5 + 8)
+                extra["config5"] = {"workload": f"n={a.c5_n}, P=100, ntree=400, (1+X4|g.1) with 200 groups: q=400, z=2 (BASELINE config 5)",
+                                    "gpu_iters_per_sec": 6 / d5, "ms_per_step": 1e3 * d5 / 6, "n_leapfrog_per_step": (n1["sum_n_leapfrog"] - n0["sum_n_leapfrog"]) / 6,
+                                    "setup_seconds": {"data + binning on the host": t5c - t5}, "hmc_mode": 0,
+                                    "roofline_tree_kernel": rf5,
+                                    "roofline_hmc": {"kernel": "k_stan_fused (direct), K=2, z=2, 400-column Z'e histogram in LDS", "avg_eval_us": l5["kernels_us"],
+                                                     "avg_eval_us_with_result_fetch": l5["with_fetch_us"],
+                                                     "algorithmic_bytes_per_eval": l5["algorithmic_bytes"],
+                                                     "frac": l5["algorithmic_bytes"] / (l5["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                     "bytes_the_kernel_reads_per_eval": read5,
+                                                     "frac_against_bytes_read": read5 / (l5["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}}
             rec["extra_configs"] = extra
         if rec["n_gpus"] != a.gpus:
             raise SystemExit(f"internal: n_gpus {rec['n_gpus']} != --gpus {a.gpus}")

@@ -104,6 +104,8 @@ typedef struct {
   int32_t hmc_mode;           /* extension: 0 = sufficient-statistic (Gram) gradient, 1 = per-leapfrog O(N) kernels */
 } s4b_stan_control;
 
+/* per-iteration callback (src/init.cpp:849-911); a non-zero return stops the run after that iteration (status 1, "stopped by the
+ * per-iteration callback") — the reference's callback is R code whose error unwinds run() */
 typedef int (*s4b_callback_fn)(void* user, const double* yhat_train, const double* yhat_test,
                                const double* stan_pars, int32_t num_pars);
 /* progress / cancellation hook of run(): called before iteration `iter` (1-based) of `num_iter` for iter = 1 and whenever iter is

@@ -301,9 +301,10 @@ class Sampler:
         sp = np.ctypeslib.as_array(stan_pars, shape=(num_pars,)).copy()
         try:
             self.callback_results.append(self._py_callback(tr, te, sp))
-        except BaseException as e:       # ctypes would swallow it: remember it, let the run finish its iteration, re-raise after
+        except BaseException as e:       # ctypes would swallow it: remember it, stop the run (non-zero return), re-raise after
             if self._pending_exc is None:
                 self._pending_exc = e
+            return 1
         return 0
 
     # ------------------------------------------------------------------ the .Call surface

@@ -1870,7 +1870,11 @@ class DevHip {
     if (d.device < 0 || d.device >= count) throw std::runtime_error("stan4bart_amd: HIP device ordinal out of range");
     device_ = d.device;
     HIP_OK(hipSetDevice(device_));
+#ifdef S4B_TUNING
+    // Environment switches of the TUNING build only (`make tuning`, libs4b_tuning.so): the release library's launch geometry — and
+    // with it the summation order of the bin sums — depends on the problem alone, never on the caller's environment
     if (const char* g = getenv("S4B_GRAPH")) useGraph_ = atoi(g) != 0;
+#endif
     HIP_OK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     HIP_OK(hipEventCreate(&evStart_)); HIP_OK(hipEventCreate(&evStop_));
     n_ = d.n; nTest_ = d.nTest; P_ = d.P; T_ = d.T; nc_ = d.nc; K_ = d.K; q_ = d.q;
@@ -1882,7 +1886,9 @@ class DevHip {
     // thread beyond; S4B_GRID overrides it (tuning experiments).  Measured on MI355X (profiles/r01_grid_sweep.txt): 1024
     // workgroups are best both at n = 1e6 (latency-bound: 11.5 us per launch) and at n = 1e7 (52 % of HBM peak)
     a.grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (nQuads + BLOCK - 1) / BLOCK));
+#ifdef S4B_TUNING
     if (const char* g = getenv("S4B_GRID")) { int v = atoi(g); if (v >= 1 && v <= GRID_MAX) a.grid = v; }
+#endif
     // the tree kernel keeps 16-bit per-thread bin counts: at most 255 quads per thread
     while ((nQuads + (int64_t)a.grid * BLOCK - 1) / ((int64_t)a.grid * BLOCK) > 255 && a.grid < GRID_MAX) a.grid *= 2;
     if ((nQuads + (int64_t)a.grid * BLOCK - 1) / ((int64_t)a.grid * BLOCK) > 255) throw std::invalid_argument("n is too large for one device (more than 255 quads per thread)");
@@ -1905,7 +1911,11 @@ class DevHip {
     a.binary = d.binary; binary_ = d.binary != 0;
     if (binary_) {
       a.lat = zalloc<double>((size_t)a.npad);
+#ifdef S4B_TUNING
       const char* lv = getenv("S4B_LATENTS");   // 1: the serial-bookkeeping kernel (k_latents), default: tables + readlane chain
+#else
+      const char* lv = nullptr;
+#endif
       if (!(lv && atoi(lv) == 1)) {
         latX_ = zalloc<double>((size_t)a.npad);
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_latents2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lat2_lds_bytes()));
@@ -1950,7 +1960,9 @@ class DevHip {
     {   // fused path (one launch per tree update, dev_step.inc): one 512-thread workgroup per CU at most
       // gridF - 1 workgroups share the observations, the last one is the control workgroup (write-backs, proposals one launch ahead)
       a.gridF = 1 + (int)std::min<int64_t>(255, std::max<int64_t>(1, (nQuads + F_PT - 1) / F_PT));
+#ifdef S4B_TUNING
       if (const char* g = getenv("S4B_GRIDF")) { int v = atoi(g); if (v >= 2 && v <= F_GRID_MAX) a.gridF = v; }
+#endif
       const int64_t passThreads = (int64_t)(a.gridF - 1) * F_PT;
       const int64_t perThread = (nQuads + passThreads - 1) / passThreads;
       a.candStride = (int64_t)cand_bytes(nc_); a.candBase = zalloc<unsigned char>((size_t)4 * cand_bytes(nc_));   // k_step: 2 parities x 2 images
@@ -2011,7 +2023,9 @@ class DevHip {
       const size_t M = (size_t)(1 + K_ + q_);
       fusedLds_ = (size_t)q_ * 16 * ((size_t)q_ * 16 * (SBLOCK / 64) <= 32768 ? SBLOCK / 64 : 1) + (size_t)(K_ + q_) * 8 + 16;
       stanFused_ = K_ <= 16 && q_ <= S_QMAX;
+#ifdef S4B_TUNING
       if (const char* f = getenv("S4B_STAN_FUSED")) stanFused_ = stanFused_ && atoi(f) != 0;
+#endif
       if (stanFused_) {
         fusedAcc_ = zalloc<unsigned long long>((size_t)2 * S_COPIES * fused_words((int)M)); fusedBad_ = zalloc<int32_t>(2);
         // (coherent: the device's stores reach host memory when they are released, not at the end of the kernel — the host polls this buffer)
@@ -2146,7 +2160,11 @@ class DevHip {
   // One sweep = 2 T + 2 launches with arguments that never change (per-tree state is reached through pointers), so
   // it is captured once into a hipGraph and replayed: the host then costs one call per sweep instead of ~4 us per launch.
   void sweep(int thin) {
+#ifdef S4B_TUNING
     static const bool dbg = getenv("S4B_HOST_TIMING") != nullptr;
+#else
+    constexpr bool dbg = false;
+#endif
     if (dbg) HIP_OK(hipEventRecord(evStart_, stream_));
     sweep_impl(thin);
     if (dbg) {
@@ -2472,14 +2490,15 @@ class DevHip {
     if (!(stanFused_ && K_ + q_ <= S_PAR_INLINE)) push_params(beta, b);
     if (stanFused_) {
       launch_stan_fused(0, 0, true);
-      if (!fetch_fused(gX, gZ, &ss)) {
+      const bool fusedOk = fetch_fused(gX, gZ, &ss);
+      if (!fusedOk) {
         if (K_ + q_ <= S_PAR_INLINE) push_params(beta, b);     // (the plain-double kernels read beta, b from device memory)
         reduce_pipeline(0, 0, 1); fetch_out(gX, gZ, &ss); recentre_scales(gX, gZ, ss);
       }
-      inlineBeta_ = nullptr; inlineB_ = nullptr;
 #ifdef S4B_FX_DEBUG
-      else {
+      if (fusedOk) {   // (debug build: every fixed-point evaluation is repeated in plain doubles and compared)
         std::vector<double> rX((size_t)K_ + 1), rZ((size_t)q_ + 1); double rs;
+        if (K_ + q_ <= S_PAR_INLINE) push_params(beta, b);
         reduce_pipeline(0, 0, 1); fetch_out(rX.data(), rZ.data(), &rs);
         double worst = std::fabs(rs - ss) / (std::fabs(rs) + 1e-300);
         for (int k = 0; k < K_; ++k) worst = std::max(worst, std::fabs(rX[k] - gX[k]) / (std::fabs(rX[k]) + 1e-12));
@@ -2487,6 +2506,7 @@ class DevHip {
         if (worst > 1e-9) fprintf(stderr, "FXDBG eval %lld: worst rel diff %.3e (ss %.17g vs %.17g) exps %d %d %d\n", (long long)fusedEvals_, worst, ss, rs, fxExp_[0], fxExp_[1], fxExp_[2]);
       }
 #endif
+      inlineBeta_ = nullptr; inlineB_ = nullptr;
     } else { reduce_pipeline(0, 0, 1); fetch_out(gX, gZ, &ss); }
     return ss;
   }
@@ -2585,6 +2605,10 @@ class DevHip {
     fxLastBad_ = fusedEvals_;
   }
   void fused_stats(int64_t out[2]) const { out[0] = fusedEvals_; out[1] = fusedFallbacks_; }
+  // The power-of-two scales of the fixed-point Stan sums follow the evaluation history.  They are put back to their initial values at
+  // every run() and set_state(), so that a chain continued in another sampler (get_state / set_state) sums with the same scales as
+  // the chain that was never interrupted: bit-identical, not just equal to 2^-67.
+  void reset_fused_scales() { fxExp_[0] = fxExp_[1] = fxExp_[2] = 0; fxLastBad_ = -2; fxTinyFail_ = false; }
   void sweep_stats(int64_t out[2]) const { out[0] = sweepCount_; out[1] = sweepHandOvers_; }
 
   // HIP-event timing of the per-leapfrog O(N) sums (hmc_mode 1 path: e = e0 - X beta - Z b, |e|^2, X'e, Z'e) on the

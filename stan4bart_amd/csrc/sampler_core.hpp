@@ -242,6 +242,7 @@ class SamplerCore {
   void run(int numIter, bool isWarmup, int resultsType, s4b_results* out) {
     live();
     if (numIter < 1) throw std::invalid_argument("num_iter must be >= 1");
+    dev_.reset_fused_scales();     // (history-independent at every call boundary: see DevHip::reset_fused_scales)
     const bool doStan = resultsType == 0 || resultsType == 2, doBart = resultsType == 0 || resultsType == 1;
     const int numPars = (int)row_.size();
     size_t slot = 0;
@@ -303,7 +304,10 @@ class SamplerCore {
           if (out->bart_varcount) var_counts(out->bart_varcount + slot * (size_t)P_);
         }
         if (keepTrees_ && !isWarmup) keep_current_trees();
-        if (callback_) callback_(callbackUser_, train.data(), nTest_ ? test.data() : nullptr, row_.data(), numPars);
+        // (a non-zero return stops the run after this iteration: the reference's callback is R code whose error unwinds run(),
+        // src/init.cpp:855)
+        if (callback_ && callback_(callbackUser_, train.data(), nTest_ ? test.data() : nullptr, row_.data(), numPars) != 0)
+          throw std::runtime_error("stopped by the per-iteration callback");
         if (timing) tph[3] += now() - t0;
       }
       if (keepFits_) ++slot;
@@ -567,6 +571,7 @@ class SamplerCore {
     }
     // ---- commit
     nuts_->set_state(ns);
+    dev_.reset_fused_scales();
     nuts_->current_row(row_.data());
     set_rng(rr);
     sigma_ = sc4[3];

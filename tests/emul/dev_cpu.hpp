@@ -243,6 +243,7 @@ class DevCpu {
   void set_tree_path(int path) { if (path < 0 || path > 4 || path == 3) throw std::invalid_argument("tree path must be 0 (automatic), 1 (two-kernel), 2 (fused) or 4 (persistent)"); pathReq_ = path; }
   void get_tree_path(int32_t out[2]) const { out[0] = pathReq_; out[1] = 1; }
   void fused_stats(int64_t out[2]) const { out[0] = 0; out[1] = 0; }
+  void reset_fused_scales() {}
   void sweep_stats(int64_t out[2]) const { out[0] = 0; out[1] = 0; }
   void profile_sweep(int nSweeps, int thin, double* out) { for (int i = 0; i < 8; ++i) out[i] = 0.0; for (int k = 0; k < nSweeps; ++k) sweep(thin); }
   void test_fits(double* out) {

@@ -300,10 +300,16 @@ def test_interface_details_of_the_call_layer(emul_lib, capfd):
     # ... and so does an exception inside the per-iteration callback
     import copy
     a2 = copy.copy(args)
-    a2.callback = lambda tr, te, sp: (_ for _ in ()).throw(ValueError("from the callback"))
+    calls = []
+
+    def bad_callback(tr, te, sp):
+        calls.append(1)
+        raise ValueError("from the callback")
+    a2.callback = bad_callback
     s = make_sampler(emul_lib, "emu_", a2)
     with pytest.raises(ValueError, match="from the callback"):
-        s.run(2, True)
+        s.run(5, True)
+    assert len(calls) == 1       # the run stops at the failing iteration (non-zero return of s4b_callback_fn), it is not called again
     s.free()
     # verbose / refresh without a hook: the reference's lines
     args.verbose, args.refresh = 2, 2
