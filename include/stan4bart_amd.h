@@ -48,6 +48,13 @@ typedef struct {
   double k;             /* normal(k = 2)                                              */
   double node_scale;    /* model@node.scale: 0.5 continuous, 3.0 binary (:477-479)    */
   double birth_or_death_prob, swap_prob, change_prob, birth_prob; /* dbarts: .5 .1 .4 .5 */
+  const double* split_probs; /* cgm(split.probs = ): NULL (predictors equally likely) or one positive weight per predictor, any scale:
+                              * a rule's predictor is drawn with probability weight / sum of the weights of the predictors still
+                              * available at the node, and the tree prior carries the same term (R/stan4bart_fit.R:466-475;
+                              * tests/testthat/test-09-bartArgs.R:20).  Tree updates then run on the two-kernel path.           */
+  int32_t use_quantiles;     /* dbartsControl(useQuantiles = ) through bart_args (R/stan4bart_fit.R:440-444): 0 uniform cut points
+                              * between the column extremes, 1 cut points from the distinct values (n_cuts is then a maximum)    */
+  int32_t reserved;
 } s4b_bart_control;
 
 /* dbartsData slots (R/lme4_functions.R:176, R/stan4bart_fit.R:449-451) */

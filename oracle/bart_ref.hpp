@@ -17,6 +17,7 @@
 
 #include <cstdint>
 #include <cstddef>
+#include <set>
 #include <vector>
 #include <cmath>
 #include <algorithm>
@@ -33,6 +34,14 @@ struct BartConfig {
   double k = 2.0;
   double nodeScale = 0.5;    // 0.5 continuous / 3.0 binary (R/stan4bart_fit.R:477-479)
   double birthOrDeathProb = 0.5, swapProb = 0.1, changeProb = 0.4, birthProb = 0.5;
+  // cgm(split.probs = ) (reference R/stan4bart_fit.R:466-475; tests/testthat/test-09-bartArgs.R:20): empty = predictors
+  // equally likely, else one positive weight per predictor.  dbarts' CGM prior then draws the predictor of a rule with probability
+  // weight / (sum of the weights of the predictors available at the node) — one uniform times that sum, the first available
+  // predictor whose cumulative weight exceeds it — and the tree prior carries log(weight) - log(sum) in place of -log(#available).
+  // PARITY UNPINNED against dbarts (restated from the published algorithm, like the rest of this file).
+  std::vector<double> splitProbs;
+  // dbartsControl(useQuantiles = ): cut points from the distinct values of a predictor instead of a uniform grid
+  bool useQuantiles = false;
 };
 
 enum StepType { STEP_BIRTH = 0, STEP_DEATH = 1, STEP_SWAP = 2, STEP_CHANGE = 3 };
@@ -257,6 +266,18 @@ class BartFit {
   void setCutPoints(const double* x, const int* nCuts) {
     numCuts.resize(p); cuts.resize(p);
     for (size_t j = 0; j < p; ++j) {
+      if (cfg.useQuantiles) {
+        // dbarts setCutPointsFromQuantiles (restated, unpinned): the sorted distinct values; at most maxCuts + 1 of them: a cut
+        // between every two neighbours; otherwise maxCuts cuts at ranks k * step + step / 2, step = #distinct / maxCuts
+        std::set<double> uniq(x + j * n, x + (j + 1) * n);
+        std::vector<double> sorted(uniq.begin(), uniq.end());
+        const size_t nu = sorted.size(), maxCuts = (size_t)nCuts[j];
+        size_t nc, step, offset;
+        if (nu <= maxCuts + 1) { nc = nu - 1; step = 1; offset = 0; } else { nc = maxCuts; step = nu / nc; offset = step / 2; }
+        numCuts[j] = (int)nc; cuts[j].resize(nc);
+        for (size_t k = 0; k < nc; ++k) { const size_t idx = std::min(k * step + offset, nu - 2); cuts[j][k] = 0.5 * (sorted[idx] + sorted[idx + 1]); }
+        continue;
+      }
       double mn = x[j * n], mx = x[j * n];
       for (size_t i = 1; i < n; ++i) { mn = std::min(mn, x[j * n + i]); mx = std::max(mx, x[j * n + i]); }
       numCuts[j] = nCuts[j];
@@ -319,7 +340,23 @@ class BartFit {
     return cfg.base / std::pow(1.0 + (double)nd->depth(), cfg.power);
   }
   int64_t unifInt(int64_t lo, int64_t hiExcl) { return lo + (int64_t)(rng->unif_rand() * (double)(hiExcl - lo)); }
+  double availableWeight(const Node* nd) const {
+    double tot = 0.0;
+    for (size_t v = 0; v < p; ++v) { int lo, hi; splitInterval(nd, (int)v, lo, hi); if (lo <= hi) tot += cfg.splitProbs[v]; }
+    return tot;
+  }
   int drawSplitVariable(const Node* nd) {
+    if (!cfg.splitProbs.empty()) {
+      const double u = rng->unif_rand() * availableWeight(nd);
+      double run = 0.0; int last = -1;
+      for (size_t v = 0; v < p; ++v) {
+        int lo, hi; splitInterval(nd, (int)v, lo, hi);
+        if (lo > hi) continue;
+        run += cfg.splitProbs[v]; last = (int)v;
+        if (run > u) return (int)v;
+      }
+      return last;
+    }
     int numGood = numAvailable(nd);
     int idx = (int)unifInt(0, numGood);
     for (size_t v = 0; v < p; ++v) { int lo, hi; splitInterval(nd, (int)v, lo, hi); if (lo <= hi) { if (idx == 0) return (int)v; --idx; } }
@@ -400,7 +437,8 @@ class BartFit {
     double pg = growthProb(nd);
     if (nd->isBottom()) return std::log(1.0 - pg);
     double r = std::log(pg);
-    r += -std::log((double)numAvailable(nd));
+    if (cfg.splitProbs.empty()) r += -std::log((double)numAvailable(nd));
+    else r += std::log(cfg.splitProbs[(size_t)nd->var]) - std::log(availableWeight(nd));
     int lo, hi; splitInterval(nd, nd->var, lo, hi);
     r += -std::log((double)(hi - lo + 1));
     return r + treeLogPrior(nd->left) + treeLogPrior(nd->right);

@@ -122,6 +122,8 @@ int orc_create(const s4b_bart_control* bc, const s4b_bart_data* bd, const s4b_st
     cfg.numTrees = bc->n_trees; cfg.thin = bc->n_thin > 0 ? bc->n_thin : 1; cfg.binary = s.binary;
     cfg.base = bc->base; cfg.power = bc->power; cfg.k = bc->k; cfg.nodeScale = bc->node_scale;
     cfg.birthOrDeathProb = bc->birth_or_death_prob; cfg.swapProb = bc->swap_prob; cfg.changeProb = bc->change_prob; cfg.birthProb = bc->birth_prob;
+    if (bc->split_probs) cfg.splitProbs.assign(bc->split_probs, bc->split_probs + bd->p);
+    cfg.useQuantiles = bc->use_quantiles != 0;
     std::vector<int> ncuts(bd->n_cuts, bd->n_cuts + bd->p);
     s.bart.reset(new BartFit(cfg, s.n, (size_t)bd->p, bd->x, sd->y, ncuts.data(), (size_t)bd->n_test, bd->x_test, &s.rrng));
     if (sd->has_weights) {

@@ -226,6 +226,7 @@ s4b_stan_control unpack_stan_control(SEXP c) {
 
 void unpack_bart(SEXP control, SEXP data, SEXP model, s4b_bart_control& bc, s4b_bart_data& bd, std::vector<int32_t>& nCuts) {
   std::memset(&bc, 0, sizeof(bc)); std::memset(&bd, 0, sizeof(bd));
+  int splitProbsLen = -1;
   // dbartsControl (dbarts R sources; R/stan4bart_fit.R:437-452 sets n.trees, n.thin, keepTrees, binary)
   bc.n_trees = Rf_asInteger(slot(control, "n.trees"));
   bc.n_thin = Rf_asInteger(slot(control, "n.thin"));
@@ -235,7 +236,24 @@ void unpack_bart(SEXP control, SEXP data, SEXP model, s4b_bart_control& bc, s4b_
   SEXP treePrior = slot(model, "tree.prior");
   bc.power = Rf_asReal(slot(treePrior, "power")); bc.base = Rf_asReal(slot(treePrior, "base"));
   SEXP nodePrior = slot(model, "node.prior");
-  bc.k = has_slot(nodePrior, "k") ? real_or(slot(nodePrior, "k"), 2.0) : 2.0;   // (a hyperprior on k is not sampled on this path)
+  bc.k = has_slot(nodePrior, "k") ? real_or(slot(nodePrior, "k"), 2.0) : 2.0;
+  // a hyperprior on k (bart_args$k = chi(...), R/stan4bart_fit.R:460-465: model@node.hyperprior is then not a fixed value) is
+  // not sampled on this path: refuse it rather than silently fixing k
+  if (has_slot(model, "node.hyperprior")) {
+    SEXP hp = slot(model, "node.hyperprior");
+    if (!Rf_isNull(hp) && has_slot(hp, "degreesOfFreedom")) Rf_error("a hyperprior on k (chi) is not supported by stan4bart_amd: pass a number as bart_args$k");
+  }
+  // cgm(split.probs = ): tree.prior@splitProbabilities, one weight per predictor (numeric(0) = equally likely)
+  if (has_slot(treePrior, "splitProbabilities")) {
+    SEXP sp = slot(treePrior, "splitProbabilities");
+    if (!Rf_isNull(sp) && Rf_xlength(sp) > 0) {
+      if (!Rf_isReal(sp)) Rf_error("tree.prior@splitProbabilities must be numeric");
+      bc.split_probs = REAL(sp);      // (length checked against data@x below; borrowed: the S4 object outlives the call)
+      splitProbsLen = (int)Rf_xlength(sp);
+    }
+  }
+  // dbartsControl(useQuantiles = ) travels through bart_args (R/stan4bart_fit.R:440-444)
+  bc.use_quantiles = (has_slot(control, "useQuantiles") && Rf_asLogical(slot(control, "useQuantiles")) == TRUE) ? 1 : 0;
   bc.node_scale = Rf_asReal(slot(model, "node.scale"));
   bc.birth_or_death_prob = Rf_asReal(slot(model, "p.birth_death")); bc.swap_prob = Rf_asReal(slot(model, "p.swap"));
   bc.change_prob = Rf_asReal(slot(model, "p.change")); bc.birth_prob = Rf_asReal(slot(model, "p.birth"));
@@ -244,6 +262,7 @@ void unpack_bart(SEXP control, SEXP data, SEXP model, s4b_bart_control& bc, s4b_
   SEXP dims = Rf_getAttrib(x, R_DimSymbol);
   if (!Rf_isReal(x) || Rf_isNull(dims) || Rf_length(dims) != 2) Rf_error("data@x must be a real matrix");
   bd.n = INTEGER(dims)[0]; bd.p = INTEGER(dims)[1]; bd.x = REAL(x);
+  if (splitProbsLen >= 0 && splitProbsLen != bd.p) Rf_error("tree.prior@splitProbabilities must have one entry per predictor");
   SEXP cuts = has_slot(data, "n.cuts") ? slot(data, "n.cuts") : Rf_getAttrib(control, Rf_install("n.cuts"));
   nCuts = ints(cuts);
   if (nCuts.size() == 1) nCuts.assign((size_t)bd.p, nCuts[0]);

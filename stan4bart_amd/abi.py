@@ -23,7 +23,8 @@ class BartControl(C.Structure):
                 ("node_capacity", C.c_int32),
                 ("base", C.c_double), ("power", C.c_double), ("k", C.c_double), ("node_scale", C.c_double),
                 ("birth_or_death_prob", C.c_double), ("swap_prob", C.c_double),
-                ("change_prob", C.c_double), ("birth_prob", C.c_double)]
+                ("change_prob", C.c_double), ("birth_prob", C.c_double),
+                ("split_probs", c_double_p), ("use_quantiles", C.c_int32), ("reserved", C.c_int32)]
 
 
 class BartData(C.Structure):
@@ -112,6 +113,8 @@ class SamplerArgs:
     keep_trees: bool = False
     node_capacity: int = 0
     proposal_probs: Sequence[float] = (0.5, 0.1, 0.4, 0.5)
+    split_probs: Optional[Sequence[float]] = None     # cgm(split.probs): one positive weight per BART predictor, or None (uniform)
+    use_quantiles: bool = False                       # dbartsControl(useQuantiles): cut points from the distinct values
     # stan data
     X: Optional[np.ndarray] = None          # n x K (already centred)
     y: Optional[np.ndarray] = None
@@ -192,7 +195,13 @@ class Sampler:
         pp = a.proposal_probs
         bc = BartControl(n_trees=a.n_trees, n_thin=a.n_thin, keep_trees=int(a.keep_trees),
                          node_capacity=a.node_capacity, base=a.base, power=a.power, k=a.k, node_scale=ns,
-                         birth_or_death_prob=pp[0], swap_prob=pp[1], change_prob=pp[2], birth_prob=pp[3])
+                         birth_or_death_prob=pp[0], swap_prob=pp[1], change_prob=pp[2], birth_prob=pp[3],
+                         use_quantiles=int(bool(a.use_quantiles)))
+        if a.split_probs is not None:
+            sp = keep(_f64(np.asarray(a.split_probs, dtype=np.float64)))
+            if sp.shape != (xb.shape[1],):
+                raise ValueError("split_probs needs one weight per BART predictor")
+            bc.split_probs = _dp(sp)
 
         X = keep(_f64(a.X if a.X is not None else np.zeros((n, 0))))
         if X.ndim == 1:

@@ -493,6 +493,8 @@ __device__ __forceinline__ double mv_log1m_pg(const WaveModel& m, int d) { retur
 __device__ __forceinline__ double mv_log_int(const WaveModel& m, int k) {
   return k < 64 ? m.li0.get(k) : (k < 128 ? m.li1.get(k - 64) : S4B_UNI(m.logInt[k]));
 }
+// (the wave-register control path has no weighted predictor choice: samplers with cgm(split.probs) take the pointer-storage path)
+__device__ __forceinline__ const double* mv_split_probs(const WaveModel&) { return nullptr; }
 __device__ __forceinline__ int mv_num_cuts(const WaveModel& m, int v) {
   return v < 64 ? __builtin_amdgcn_readlane(m.nc0, v) : (v < 128 ? __builtin_amdgcn_readlane(m.nc1, v - 64) : S4B_UNI(m.numCuts[v]));
 }
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
       const int prHwm = g.i32(7), nbAll = g.i32(5) + g.i32(6), hwmT = g.i32(32 + TI_HWM), hwmN = g.i32(40 + TI_HWM);
       int need = prHwm > hwmT ? prHwm : hwmT;
       if (doPropose && hwmN + 2 > need) need = hwmN + 2;
-      const bool wavePath = need <= 64 && nbAll <= 64 && need <= nc + 2;
+      const bool wavePath = need <= 64 && nbAll <= 64 && need <= nc + 2 && a.model.splitProbs == nullptr;
       if (wavePath) {
         for (int b = ridx + 2 * RT; b < a.grid; b += RT) {
 #pragma unroll
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(CBLOCK) void k_control(BartArrays a, int t, int nex
   int need = 0, nb = 0;
   if (doDecide) { need = prT.hwm > hwmT ? prT.hwm : hwmT; nb = prT.nbA + prT.nbB; }
   if (doPropose && hwmN + 2 > need) need = hwmN + 2;
-  const bool wavePath = need <= 64 && nb <= 64 && need <= nc + 2;
+  const bool wavePath = need <= 64 && nb <= 64 && need <= nc + 2 && a.model.splitProbs == nullptr;   // (cgm(split.probs): the pointer-storage control code)
   // generator positions decide(t) can end at; candidate 1 only exists when accepting changes the number of leaves
   const int drawsAccept = (doDecide && prT.status == 1) ? 1 : 0;
   const int nlNow = prT.nbA;
@@ -1969,7 +1971,8 @@ class DevHip {
       ldsStep_ = step_lds_bytes(nc_, d.weights != nullptr);
       // automatic choice: the fused launch wins while a tree update is latency-bound; at large n the two-kernel path keeps
       // more waves streaming (4 per SIMD instead of 2)
-      fusedOk_ = perThread <= 255 && ldsStep_ + 24 * 1024 <= 160 * 1024;
+      // (cgm(split.probs): the weighted predictor choice lives in the pointer-storage control code only — two kernels per tree)
+      fusedOk_ = perThread <= 255 && ldsStep_ + 24 * 1024 <= 160 * 1024 && d.model.splitProbs == nullptr;
       fusedAuto_ = perThread <= 8 && fusedOk_;
       a.partF = zalloc<double>((size_t)2 * 3 * a.binCap * a.gridF);
       // persistent sweep (dev_sweep.inc): ONE launch per sweep, the residual in registers, every workgroup deciding redundantly.
@@ -1992,6 +1995,7 @@ class DevHip {
     int32_t* nc = alloc<int32_t>((size_t)P_); upload(nc, d.numCuts, (size_t)P_); a.numCuts = nc;
     a.trace = zalloc<StepRecord>((size_t)std::max(1, d.traceCap)); a.traceCount = zalloc<int32_t>(1); a.errFlag = zalloc<int32_t>(1);
     a.model = d.model; a.model.numCuts = nc; a.traceOn = 0; a.model.scratch = nullptr;
+    if (d.model.splitProbs) { double* sp = alloc<double>((size_t)P_); upload(sp, d.model.splitProbs, (size_t)P_); a.model.splitProbs = sp; }
     { double* tb = alloc<double>(3 * S4B_MAX_DEPTH); upload(tb, d.model.pgDepth, (size_t)S4B_MAX_DEPTH); upload(tb + S4B_MAX_DEPTH, d.model.logPg, (size_t)S4B_MAX_DEPTH);
       upload(tb + 2 * S4B_MAX_DEPTH, d.model.log1mPg, (size_t)S4B_MAX_DEPTH);
       a.model.pgDepth = tb; a.model.logPg = tb + S4B_MAX_DEPTH; a.model.log1mPg = tb + 2 * S4B_MAX_DEPTH;

@@ -172,7 +172,7 @@ class SamplerCore {
     // ---- BART data: cut points + binning on the host (one-off), model constants
     numCuts_.assign(bd->n_cuts, bd->n_cuts + P_);
     for (int j = 0; j < P_; ++j) if (numCuts_[(size_t)j] < 0 || numCuts_[(size_t)j] > 65534) throw std::invalid_argument("n_cuts must be in [0, 65534]");
-    make_cuts(bd->x);
+    make_cuts(bd->x, bc->use_quantiles != 0);
     std::vector<uint16_t> xbin((size_t)P_ * n_), xbinTest((size_t)P_ * nTest_);
     bin_matrix(bd->x, n_, xbin);
     if (nTest_) bin_matrix(bd->x_test, nTest_, xbinTest);
@@ -184,7 +184,12 @@ class SamplerCore {
     di.model.P = P_; di.model.Pvalid = 0;
     for (int j = 0; j < P_; ++j) if (numCuts_[(size_t)j] > 0) ++di.model.Pvalid;
     if (di.model.Pvalid == 0) throw std::invalid_argument("no predictor has a cut point");
-    di.model.numCuts = nullptr; di.model.scratch = nullptr;
+    di.model.numCuts = nullptr; di.model.scratch = nullptr; di.model.splitProbs = nullptr;
+    if (bc->split_probs) {   // cgm(split.probs = ): one positive weight per predictor (reference R/stan4bart_fit.R:466-475)
+      splitProbs_.assign(bc->split_probs, bc->split_probs + P_);
+      for (double w : splitProbs_) if (!(w > 0.0) || !std::isfinite(w)) throw std::invalid_argument("split_probs must be positive and finite");
+      di.model.splitProbs = splitProbs_.data();
+    }
     di.model.base = bc->base; di.model.power = bc->power;
     di.model.pBD = bc->birth_or_death_prob; di.model.pSwap = bc->swap_prob; di.model.pChange = bc->change_prob; di.model.pBirth = bc->birth_prob;
     { double sd_mu = bc->node_scale / (bc->k * std::sqrt((double)T_)); di.model.leafPrec = 1.0 / (sd_mu * sd_mu); }
@@ -676,13 +681,34 @@ class SamplerCore {
     return 1;                                                        // bart fit
   }
 
-  void make_cuts(const double* x) {   // uniform cut points between the column extremes
+  // cut points of every predictor: uniform between the column extremes (dbartsControl useQuantiles = FALSE, the default), or
+  // from the distinct values (useQuantiles = TRUE; forwarded by bart_args, reference R/stan4bart_fit.R:440-444): with at most
+  // n.cuts + 1 distinct values a cut between every two neighbours, otherwise n.cuts cuts at evenly spaced ranks of the sorted
+  // distinct values, each half-way between two neighbours.  (dbarts' rule restated: unpinned)  The cut COUNT of a
+  // predictor may shrink below n.cuts then.
+  void make_cuts(const double* x, bool quantiles) {
     cuts_.resize((size_t)P_);
     for (int j = 0; j < P_; ++j) {
       const double* col = x + (size_t)j * n_;
+      int m = numCuts_[(size_t)j];
+      if (quantiles) {
+        std::vector<double> u(col, col + n_);
+        std::sort(u.begin(), u.end());
+        u.erase(std::unique(u.begin(), u.end()), u.end());
+        const size_t nu = u.size();
+        size_t numCuts, step, offset;
+        if (nu <= (size_t)m + 1) { numCuts = nu - 1; step = 1; offset = 0; }
+        else { numCuts = (size_t)m; step = nu / numCuts; offset = step / 2; }
+        cuts_[(size_t)j].resize(numCuts);
+        for (size_t k = 0; k < numCuts; ++k) {
+          const size_t idx = std::min(k * step + offset, nu - 2);
+          cuts_[(size_t)j][k] = 0.5 * (u[idx] + u[idx + 1]);
+        }
+        numCuts_[(size_t)j] = (int32_t)numCuts;
+        continue;
+      }
       double mn = col[0], mx = col[0];
       for (size_t i = 1; i < n_; ++i) { if (col[i] < mn) mn = col[i]; if (col[i] > mx) mx = col[i]; }
-      int m = numCuts_[(size_t)j];
       cuts_[(size_t)j].resize((size_t)m);
       for (int c = 0; c < m; ++c) cuts_[(size_t)j][(size_t)c] = mn + (double)(c + 1) * (mx - mn) / (double)(m + 1);
     }
@@ -813,7 +839,7 @@ class SamplerCore {
   std::vector<double> userOffset_;
   s4b_callback_fn callback_ = nullptr; void* callbackUser_ = nullptr;
   MTState rng_;
-  std::vector<int32_t> numCuts_; std::vector<std::vector<double>> cuts_;
+  std::vector<int32_t> numCuts_; std::vector<std::vector<double>> cuts_; std::vector<double> splitProbs_;
   std::vector<double> pgDepth_, logPg_, log1mPg_, logInt_;
   ModelView hostModelView_;
   std::unique_ptr<HostModel> model_; std::unique_ptr<Nuts> nuts_;

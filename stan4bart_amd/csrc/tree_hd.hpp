@@ -70,6 +70,11 @@ struct ModelView {
   const double* logInt;      // [logIntLen]  log((double)k), k >= 1
   int32_t logIntLen;
   double* scratch;           // optional [S4B_MAX_DEPTH] work array (device: LDS); nullptr -> stack
+  // cgm(split.probs = ): unnormalised probability of every predictor (reference R/stan4bart_fit.R:466-475 forwards it to dbarts'
+  // tree prior; tests/testthat/test-09-bartArgs.R:20) or nullptr = uniform.  With it the variable of a rule is drawn with
+  // probability p_v / sum of p over the predictors still available at the node, and the tree prior carries the same term.
+  // Only the pointer-storage control code supports it (the wave-register path is compiled without: mv_split_probs).
+  const double* splitProbs;
 };
 enum { S4B_MAX_DEPTH = 128 };
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -84,6 +89,7 @@ S4B_HD inline double mv_log_pg(const ModelView& m, int d) { return S4B_UNI(m.log
 S4B_HD inline double mv_log1m_pg(const ModelView& m, int d) { return S4B_UNI(m.log1mPg[d]); }
 S4B_HD inline double mv_log_int(const ModelView& m, int k) { return S4B_UNI(m.logInt[k]); }
 S4B_HD inline int mv_num_cuts(const ModelView& m, int v) { return S4B_UNI(m.numCuts[v]); }
+S4B_HD inline const double* mv_split_probs(const ModelView& m) { return m.splitProbs; }
 
 
 // everything the O(N) kernels and decide() need to know about the pending move of one tree
@@ -195,6 +201,23 @@ template <class TR, class MV> S4B_HD inline double tv_growth(const TR& t, const 
   return mv_pg_depth(m, tv_depth_of(t, n));
 }
 
+// cgm(split.probs): sum of the predictor probabilities over the predictors that still have a free cut at node n
+template <class TR, class MV> S4B_HD inline double tv_avail_prob_sum(const TR& t, const MV& m, int n, const double* sp) {
+  double tot = 0.0;
+  for (int v = 0; v < m.P; ++v) {
+    if (mv_num_cuts(m, v) <= 0) continue;
+    int lo, hi; tv_interval(t, m, n, v, lo, hi);
+    if (lo <= hi) tot += sp[v];
+  }
+  return tot;
+}
+// log P(variable v | node n) of the tree prior: -log(#available) when the predictors are equally likely
+template <class TR, class MV> S4B_HD inline double tv_log_var_prob(const TR& t, const MV& m, int n, int v, int na) {
+  const double* sp = mv_split_probs(m);
+  if (!sp) return -mv_log_int(m, na);
+  return log(sp[v]) - log(tv_avail_prob_sum(t, m, n, sp));
+}
+
 // the idx-th (0-based) predictor, in increasing order, that is available at node n
 template <class TR, class MV> S4B_HD inline int tv_nth_avail_var(const TR& t, const MV& m, int n, int idx) {
   if (m.Pvalid == m.P) {
@@ -224,6 +247,20 @@ template <class TR, class MV> S4B_HD inline int tv_nth_avail_var(const TR& t, co
 }
 
 template <class TR, class MV, class RNG> S4B_HD inline int tv_draw_var(const TR& t, const MV& m, int n, RNG* rng) {
+  if (const double* sp = mv_split_probs(m)) {
+    // weighted: u * (sum over the available predictors), the first predictor whose running sum exceeds it (one uniform, like the
+    // unweighted draw)
+    const double u = r_unif(rng) * tv_avail_prob_sum(t, m, n, sp);
+    double run = 0.0; int last = -1;
+    for (int v = 0; v < m.P; ++v) {
+      if (mv_num_cuts(m, v) <= 0) continue;
+      int lo, hi; tv_interval(t, m, n, v, lo, hi);
+      if (lo > hi) continue;
+      run += sp[v]; last = v;
+      if (run > u) return v;
+    }
+    return last;
+  }
   int good = tv_num_avail(t, m, n);
   int idx = r_unif_int(rng, 0, good);
   return tv_nth_avail_var(t, m, n, idx);
@@ -287,7 +324,7 @@ template <class TR, class MV> S4B_HD inline double tv_log_prior(const TR& t, con
     } else if (k == 1) {
       int na = tv_num_avail(t, m, nd);
       double r = na == 0 ? -INFINITY : mv_log_pg(m, depth);
-      r += -mv_log_int(m, na);
+      r += tv_log_var_prob(t, m, nd, (int)t.var.get(nd), na);
       int lo, hi; tv_interval(t, m, nd, t.var.get(nd), lo, hi);
       int width = hi - lo + 1;
       r += (width >= 1 && width < m.logIntLen) ? -mv_log_int(m, width) : -log((double)width);
@@ -307,7 +344,7 @@ template <class TR, class MV> S4B_HD inline double tv_log_prior_own(const TR& t,
   int na = tv_num_avail(t, m, nd);
   if (t.var.get(nd) == NODE_LEAF) return na == 0 ? 0.0 : mv_log1m_pg(m, depth);
   double r = na == 0 ? -INFINITY : mv_log_pg(m, depth);
-  r += -mv_log_int(m, na);
+  r += tv_log_var_prob(t, m, nd, (int)t.var.get(nd), na);
   int lo, hi; tv_interval(t, m, nd, t.var.get(nd), lo, hi);
   int width = hi - lo + 1;
   r += (width >= 1 && width < m.logIntLen) ? -mv_log_int(m, width) : -log((double)width);
@@ -429,14 +466,14 @@ S4B_HD inline bool tv_subtree_pass(const TR& cur, TR& pt, const MV& m, int nd, b
     if (checkRules && (sP < loP || sP > hiP)) return false;
     {
       double r = naC == 0 ? -INFINITY : mv_log_pg(m, depth);
-      r += -mv_log_int(m, naC);
+      r += tv_log_var_prob(cur, m, node, (int)cur.var.get(node), naC);
       const int width = hiC - loC + 1;
       r += (width >= 1 && width < m.logIntLen) ? -mv_log_int(m, width) : -log((double)width);
       sc += r;
     }
     {
       double r = naP == 0 ? -INFINITY : mv_log_pg(m, depth);
-      r += -mv_log_int(m, naP);
+      r += tv_log_var_prob(pt, m, node, (int)pt.var.get(node), naP);
       const int width = hiP - loP + 1;
       r += (width >= 1 && width < m.logIntLen) ? -mv_log_int(m, width) : -log((double)width);
       sp += r;

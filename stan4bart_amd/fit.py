@@ -159,6 +159,38 @@ def init_fit(y, Xc, groups, n, is_binary):
     return mu, 1.0
 
 
+def _fixed_k(k) -> float:
+    """bart_args$k: a number (normal(k), reference R/stan4bart_fit.R:460-465).  dbarts also takes a hyperprior call there (chi(...)):
+    sampling k is not part of this path — refuse it instead of silently fixing k."""
+    if isinstance(k, (int, float, np.integer, np.floating)):
+        return float(k)
+    raise NotImplementedError("bart_args['k'] must be a number: a hyperprior on k (dbarts chi(degreesOfFreedom, scale)) is not sampled on this path")
+
+
+def _split_probs(sp, p: int, names=None):
+    """cgm(split.probs = ) the way dbarts takes it (reference tests/testthat/test-09-bartArgs.R:20: c(X3 = 2, .default = 1)): a
+    sequence of p weights, or a mapping predictor (0-based column index, or its name when bart_args['predictor.names'] is given)
+    -> weight with an optional '.default' for the rest (1 otherwise).  Returns p positive weights summing to one, or None."""
+    if sp is None:
+        return None
+    if isinstance(sp, dict):
+        out = np.full(p, float(sp.get(".default", 1.0)))
+        for key, w in sp.items():
+            if key == ".default":
+                continue
+            j = list(names).index(key) if (names is not None and not isinstance(key, (int, np.integer))) else int(key)
+            if not 0 <= j < p:
+                raise ValueError(f"split.probs: no predictor {key!r}")
+            out[j] = float(w)
+    else:
+        out = np.asarray(sp, dtype=np.float64)
+        if out.shape != (p,):
+            raise ValueError("split.probs needs one weight per BART predictor (or a mapping with '.default')")
+    if not np.all(np.isfinite(out)) or np.any(out <= 0):
+        raise ValueError("split.probs must be positive and finite")
+    return out / out.sum()          # (dbarts hands its sampler the normalised weights)
+
+
 def make_sampler_args(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_test=None, family: str = "gaussian",
                       iter: int = 2000, warmup: int = 1000, skip=1, keep_fits: bool = True, callback=None,
                       offset=None, offset_type: str = "default", weights=None,
@@ -224,7 +256,9 @@ def make_sampler_args(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_tes
         x_bart=np.asarray(x_bart, dtype=np.float64), x_test=x_test,
         n_trees=int(bart_args.get("n.trees", 75)), n_cuts=bart_args.get("n.cuts", 100), n_thin=skip_bart,
         base=float(bart_args.get("base", 0.95)), power=float(bart_args.get("power", 2.0)),
-        k=float(bart_args.get("k", 2.0)), keep_trees=bool(bart_args.get("keepTrees", False)),
+        k=_fixed_k(bart_args.get("k", 2.0)), keep_trees=bool(bart_args.get("keepTrees", False)),
+        split_probs=_split_probs(bart_args.get("split.probs"), np.asarray(x_bart).shape[1], bart_args.get("predictor.names")),
+        use_quantiles=bool(bart_args.get("useQuantiles", False)),
         node_scale=3.0 if is_binary else 0.5,
         X=Xc, y=y, weights=weights, is_binary=is_binary, prior_dist=prior_dist, prior_dist_for_aux=0 if is_binary else 3,
         prior_scale=prior_scale, prior_mean=prior_mean, prior_df=prior_df, num_normals=num_normals, **hs_args,

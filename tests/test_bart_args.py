@@ -1,0 +1,122 @@
+"""Arguments of bart_args beyond the tree count (reference tests/testthat/test-09-bartArgs.R): cgm(split.probs = ), dbartsControl(useQuantiles = ),
+and the k hyperprior the path does not carry.  CPU side: the product's host logic over the emulated device layer against the oracle, the
+closed-form properties of the two options, and the refusals."""
+import numpy as np
+import pytest
+
+from conftest import assert_chain_parity, friedman_case, run_chain
+
+
+def bart_args_cases():
+    """(name, keyword arguments of friedman_case); shared with the `-m gpu` twin in test_gpu_parity.py."""
+    return [
+        # the reference's own call: test-09-bartArgs.R:20 `split.probs = c(X3 = 2, .default = 1)` (X3 is the third BART column)
+        ("split_probs_reference_call", dict(n=120, ranef=False, bart_args={"split.probs": {"X3": 2, ".default": 1},
+                                                                               "predictor.names": ["X1", "X2", "X3", "X5", "X6", "X7", "X8", "X9", "X10"]})),
+        ("split_probs_vector", dict(n=300, ranef=True, warmup=9, iter=30, bart_args={"split.probs": [5, 1, 1, 0.2, 1, 1, 3, 1, 0.01], "n.trees": 7})),
+        ("split_probs_deep", dict(n=500, ranef=False, warmup=10, iter=40, bart_args={"split.probs": {0: 4, 4: 0.5}, "base": 0.99, "power": 0.5, "n.trees": 5})),
+        ("quantile_cuts", dict(n=250, ranef=True, bart_args={"useQuantiles": True, "n.cuts": 20})),
+        ("quantile_cuts_few_distinct", dict(n=90, ranef=False, warmup=9, iter=25, bart_args={"useQuantiles": True, "n.cuts": 100, "n.trees": 6})),
+        ("quantile_cuts_and_split_probs", dict(n=400, ranef=True, slopes=True, n_test=17,
+                                               bart_args={"useQuantiles": True, "n.cuts": 7, "split.probs": {2: 3.0}, "n.trees": 9})),
+    ]
+
+
+@pytest.mark.parametrize("name,kw", bart_args_cases(), ids=[c[0] for c in bart_args_cases()])
+def test_host_logic_matches_oracle(oracle_lib, emul_lib, name, kw):
+    args, _ = friedman_case(**kw)
+    a = run_chain(oracle_lib, "orc_", args)
+    b = run_chain(emul_lib, "emu_", args)
+    assert_chain_parity(a, b)
+
+
+def test_split_probs_reach_the_sampler():
+    from stan4bart_amd.fit import _split_probs
+    w = _split_probs({"X3": 2, ".default": 1}, 4, ["X1", "X2", "X3", "X4"])
+    np.testing.assert_allclose(w, np.array([1, 1, 2, 1]) / 5.0)
+    np.testing.assert_allclose(_split_probs([1, 3], 2), [0.25, 0.75])
+    np.testing.assert_allclose(_split_probs({1: 9.0}, 3), np.array([1, 9, 1]) / 11.0)
+    assert _split_probs(None, 3) is None
+    for bad in ([1, 2, 3], {7: 1.0}, [1.0, -1.0], [0.0, 1.0], [np.nan, 1.0], {"X9": 2}):
+        with pytest.raises(ValueError):
+            _split_probs(bad, 2, ["X1", "X2"])
+    args, _ = friedman_case(n=50, ranef=False, bart_args={"split.probs": {1: 2.0}})
+    np.testing.assert_allclose(args.split_probs, np.array([1, 2, 1, 1, 1, 1, 1, 1, 1]) / 10.0)
+    assert args.use_quantiles is False
+
+
+def test_split_probs_shift_the_rules(oracle_lib, emul_lib):
+    """A predictor with (almost) all the weight takes (almost) all the rules; equal weights reproduce the unweighted prior's
+    acceptance arithmetic up to the draw of the predictor (one uniform instead of one integer draw, so not the same chain)."""
+    heavy = np.full(9, 1e-6); heavy[5] = 1.0
+    args, _ = friedman_case(n=200, ranef=False, warmup=20, iter=60, bart_args={"split.probs": heavy, "n.trees": 10})
+    for lib, prefix in ((oracle_lib, "orc_"), (emul_lib, "emu_")):
+        out = run_chain(lib, prefix, args, results_type=1)
+        vc = out["sample"]["bart"]["varcount"].sum(axis=1)
+        assert vc.sum() > 0 and vc[5] >= 0.99 * vc.sum(), vc
+
+
+def test_quantile_cut_points_closed_form(oracle_lib, emul_lib):
+    """Few distinct values: a cut between every two neighbours; many: maxCuts cuts at ranks k * step + step / 2 of the sorted distinct
+    values (oracle/bart_ref.hpp setCutPoints).  Read back through the rules of the sampled trees: every split value is one of them."""
+    from stan4bart_amd import make_sampler_args
+    g = np.random.default_rng(5)
+    n = 300
+    x0 = g.integers(0, 4, size=n).astype(np.float64)            # 4 distinct -> cuts 0.5, 1.5, 2.5
+    x1 = np.round(g.normal(size=n), 1)                           # ~50 distinct, 10 cuts requested
+    xb = np.column_stack([x0, x1])
+    y = np.sin(x1) + 0.5 * x0 + 0.1 * g.normal(size=n)
+    args = make_sampler_args(y, xb, X=g.random(n)[:, None], groups=[], iter=40, warmup=10,
+                             bart_args={"n.trees": 8, "useQuantiles": True, "n.cuts": [10, 10]})
+    u = np.unique(x1); nu = len(u); step = nu // 10; off = step // 2
+    idx = np.minimum(np.arange(10) * step + off, nu - 2)
+    expect = {0: np.array([0.5, 1.5, 2.5]), 1: 0.5 * (u[idx] + u[idx + 1])}
+    outs = [run_chain(oracle_lib, "orc_", args, results_type=1), run_chain(emul_lib, "emu_", args, results_type=1)]
+    assert_chain_parity(outs[0], outs[1], stan=False)
+    for lib, prefix in ((oracle_lib, "orc_"), (emul_lib, "emu_")):
+        cuts = exported_cut_points(lib, prefix, args)
+        assert len(cuts) == 2
+        for j in range(2):
+            np.testing.assert_allclose(cuts[j], expect[j], rtol=0, atol=1e-14)
+    for out in outs:            # and the rules of the sampled trees index into them
+        tr = out["trees"]
+        rules = tr["var"] >= 0
+        assert rules.sum() > 0
+        for v, k in zip(tr["var"][rules], tr["split"][rules]):
+            assert 0 <= k < len(expect[int(v)])
+
+
+def exported_cut_points(lib, prefix, args):
+    """The cut points a sampler holds, read from its exported BART state (stan4bart_exportBARTState; each implementation has its own
+    byte layout: oracle/gibbs_ref.cpp orc_export_bart_state, stan4bart_amd/csrc/sampler_core.hpp export_state)."""
+    from conftest import make_sampler
+    s = make_sampler(lib, prefix, args)
+    try:
+        blob = s.export_bart_state()
+    finally:
+        s.free()
+    P = args.x_bart.shape[1] if hasattr(args, "x_bart") else None
+    out = []
+    if prefix == "orc_":
+        assert np.frombuffer(blob, dtype=np.uint32, count=1)[0] == 0x5343524F
+        P = int(np.frombuffer(blob, dtype=np.uint64, count=1, offset=4)[0]); o = 4 + 8 + 4 + 4 + 8
+        for _ in range(P):
+            nc = int(np.frombuffer(blob, dtype=np.int32, count=1, offset=o)[0]); o += 4
+            out.append(np.frombuffer(blob, dtype=np.float64, count=nc, offset=o).copy() if nc else np.zeros(0)); o += 8 * nc
+    else:
+        head = np.frombuffer(blob, dtype=np.uint32, count=5)
+        P = int(head[2]); o = 20 + 16
+        ncs = np.frombuffer(blob, dtype=np.int32, count=P, offset=o).tolist(); o += 4 * P
+        for nc in ncs:
+            out.append(np.frombuffer(blob[o:o + 8 * nc], dtype=np.float64).copy()); o += 8 * nc
+    return out
+
+
+def test_k_hyperprior_is_refused():
+    """bart_args = list(k = chi(1.25, Inf)) (test-09-bartArgs.R:32): dbarts then resamples k every iteration — a sampler step SURVEY.md §8
+    leaves out; the fit refuses it by name instead of silently fixing k."""
+    for k in ("chi(1.25, Inf)", {"chi": (1.25, np.inf)}, None):
+        with pytest.raises(NotImplementedError, match="hyperprior"):
+            friedman_case(n=50, ranef=False, bart_args={"k": k})
+    args, _ = friedman_case(n=50, ranef=False, bart_args={"k": 3})
+    assert args.k == 3.0

@@ -1,8 +1,8 @@
 """Seeded random configurations: the HIP path against the oracle on shapes nobody wrote down by hand.
 
 Every case draws its own problem (observations 4 … 40000, 1 … 69 predictors of mixed kinds — continuous, binary, few-level,
-duplicated —, 1 … 20 trees, cut counts 1 … 100, shallow and deep tree priors, weights, probit, grouping terms, test rows,
-thinning) from `numpy.random.default_rng(seed)` and runs it on each of the three tree-update paths.  Same bar as
+duplicated —, 1 … 20 trees, cut counts 1 … 100 on a uniform grid or at quantiles, shallow and deep tree priors, predictor weights
+(split.probs), observation weights, probit, grouping terms, test rows, thinning) from `numpy.random.default_rng(seed)` and runs it on each of the three tree-update paths.  Same bar as
 test_gpu_parity.py: trace / trees / generator state bit-exact, floating-point state to 1e-6.
 """
 import numpy as np
@@ -55,6 +55,11 @@ def random_case(seed):
     bart_args = {"n.trees": int(g.integers(1, 21)), "n.cuts": int(g.choice([1, 2, 5, 100])), "k": float(g.choice([0.5, 2.0, 4.0]))}
     if deep:
         bart_args.update(base=0.99, power=0.5)
+    g2 = np.random.default_rng(77000 + seed)       # (options added later draw from their own stream: the earlier cases stay what they were)
+    if g2.random() < 0.2:
+        bart_args["split.probs"] = np.exp(g2.normal(size=p) * g2.choice([0.3, 2.0]))
+    if g2.random() < 0.2:
+        bart_args["useQuantiles"] = True
     warmup = int(g.integers(2, 12))
     it = warmup + int(g.integers(4, 40 if deep else 25))
     n_test = int(g.integers(0, 3)) * int(g.integers(1, min(n, 20)))
@@ -70,7 +75,9 @@ def random_case(seed):
     capacity = bool(g.random() < 0.1)
     if capacity:
         args.node_capacity = 3000          # (the control code's global-memory path)
-    return args, joint, dict(n=n, p=p, binary=binary, ranef=ranef, deep=deep, joint=joint, weights=weights is not None, capacity=capacity, **bart_args)
+    what = {k: v for k, v in bart_args.items() if k != "split.probs"}
+    return args, joint, dict(n=n, p=p, binary=binary, ranef=ranef, deep=deep, joint=joint, weights=weights is not None, capacity=capacity,
+                             split_probs="split.probs" in bart_args, **what)
 
 
 @pytest.mark.parametrize("path", PATHS)
@@ -81,9 +88,10 @@ def test_random_configuration(oracle_lib, hip_lib, seed, path):
     a = run_chain(oracle_lib, "orc_", args, results_type=rt)
     # (the oracle takes no hmc_mode: both modes must reproduce it)
     b = run_chain(hip_lib, "s4b_", args, results_type=rt, tree_path=path)
-    # (the persistent sweep has no weighted instantiation and needs the fused launch's LDS budget for its hand-over: there the sampler
+    # (predictor weights run on the two-kernel path's pointer-storage control code;
+    # the persistent sweep has no weighted instantiation and needs the fused launch's LDS budget for its hand-over: there the sampler
     # reports the path it took instead — s4b_get_tree_path returns both)
-    assert b["tree_path"][0] == path and (b["tree_path"][1] == path or what["weights"] or what["capacity"]), (what, b["tree_path"])
+    assert b["tree_path"][0] == path and (b["tree_path"][1] == path or what["weights"] or what["capacity"] or what["split_probs"]), (what, b["tree_path"])
     try:
         assert_chain_parity(a, b, stan=joint)
     except AssertionError as e:

@@ -363,3 +363,25 @@ def test_response_scale_extremes(oracle_lib, hip_lib, scale, hmc_mode):
     finally:
         s.free()
     assert e1 - e0 >= 40 and f1 - f0 <= 2 + (e1 - e0) // 50, (e0, f0, e1, f1)
+
+
+def _bart_args_cases():
+    from test_bart_args import bart_args_cases
+    big = [("split_probs_n20000", dict(n=20000, ranef=False, warmup=8, iter=20, bart_args={"split.probs": {0: 3.0, 4: 0.3}, "n.trees": 20})),
+           ("quantile_cuts_n20000", dict(n=20000, ranef=False, warmup=8, iter=20, bart_args={"useQuantiles": True, "n.cuts": 64, "n.trees": 20}))]
+    return bart_args_cases() + big
+
+
+@pytest.mark.parametrize("path", ["persistent", "fused", "two-kernel"])
+@pytest.mark.parametrize("name,kw", _bart_args_cases(), ids=[c[0] for c in _bart_args_cases()])
+def test_split_probs_and_quantile_cuts(oracle_lib, hip_lib, name, kw, path):
+    """cgm(split.probs = ) (reference tests/testthat/test-09-bartArgs.R:20) and dbartsControl(useQuantiles = ) on every tree path:
+    weighted predictor draws run on the pointer-storage control code of the two-kernel path (k_control), whatever path was asked for —
+    s4b_get_tree_path reports both."""
+    args, _ = friedman_case(**kw)
+    joint = kw["n"] <= 1000
+    a = run_chain(oracle_lib, "orc_", args, results_type=0 if joint else 1)
+    b = run_chain(hip_lib, "s4b_", args, results_type=0 if joint else 1, tree_path=path)
+    assert b["tree_path"][0] == path
+    assert_chain_parity(a, b, stan=joint)
+    assert b["tree_path"][1] == ("two-kernel" if "split.probs" in kw["bart_args"] else path)
