@@ -381,19 +381,20 @@ __device__ __forceinline__ void bins_loglik(const WaveArrD& binCnt, const WaveAr
   const double c = binCnt.mine();
   out.load(c == 0.0 ? 0.0 : leaf_loglik(binWt.mine(), binSum.mine(), sigma2, prec));
 }
+// value of one leaf from its statistics (weight w, weighted sum s) and the two uniforms of its draw (tree_hd.hpp leaves_draw)
+__device__ __forceinline__ double leaf_value(double w, double s, double u1, double u2, double sigma2, double prec) {
+  const double BIG = 134217728.0;
+  const double z = r_qnorm(((double)(int)(BIG * u1) + u2) / BIG);
+  const double postPrec = w / sigma2;
+  const double mean = postPrec * (s / w) / (prec + postPrec);
+  const double sd = 1.0 / sqrt(prec + postPrec);
+  return mean + sd * z;
+}
 __device__ __forceinline__ void leaves_draw(const WaveArrD& lc, const WaveArrD& ls, const WaveArrD& lw, const WaveArrD& u1, const WaveArrD& u2, int nl,
                                             double sigma2, double prec, WaveArrD& out) {
   const double c = lc.mine();
   double v = 0.0;
-  if ((int)(threadIdx.x & 63) < nl && c != 0.0) {
-    const double BIG = 134217728.0;
-    const double z = r_qnorm(((double)(int)(BIG * u1.mine()) + u2.mine()) / BIG);
-    const double w = lw.mine();
-    const double postPrec = w / sigma2;
-    const double mean = postPrec * (ls.mine() / w) / (prec + postPrec);
-    const double sd = 1.0 / sqrt(prec + postPrec);
-    v = mean + sd * z;
-  }
+  if ((int)(threadIdx.x & 63) < nl && c != 0.0) v = leaf_value(lw.mine(), ls.mine(), u1.mine(), u2.mine(), sigma2, prec);
   out.load(v);
 }
 
@@ -2390,12 +2391,23 @@ class DevHip {
       if (ho == sweepHandOvers_) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_)); sum += ms * 1000.0; ++cnt; }
     }
 #ifdef S4B_SWEEP_TIMING
-    { unsigned long long h[40]; sweep_timing_fetch(h);
+    { unsigned long long h[64]; sweep_timing_fetch(h);
       const double k = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0;
       fprintf(stderr, "SWEEP workgroup 100 (avg over %llu steps, %.2f bins, %llu routed after the decision) | pass waves, us after the previous publish: totals gathered (wave 3) %.2f; wave 4: images there %.2f, routed %.2f, tables + proposal there %.2f, arithmetic done %.2f; published (wave 3) = step %.2f | decider, us after its previous step: totals seen %.2f, verdict %.2f, tables out %.2f, step end %.2f | image wave 1, us after its previous image: starts drawing %.2f, drawn %.2f\n",
               h[0], h[0] ? (double)h[7] / (double)h[0] : 0.0, h[8], h[1] * k, h[2] * k, h[3] * k, h[4] * k, h[5] * k, h[6] * k, h[9] * k, h[10] * k, h[11] * k, h[12] * k, h[13] * k, h[14] * k);
+      fprintf(stderr, "SWEEP steps whose leaf values went out with the verdict (move not accepted, wave 3's values): %llu of %llu\n", h[35], h[0]);
+      { auto A = [&](int i) { return (double)(long long)h[i] * k; };
+        fprintf(stderr, "SWEEP timeline of a step, us after this workgroup saw the totals complete: wave 3's leaf values %.2f | decider: sees totals %.2f, verdict + old values out %.2f, new values out %.2f | proposal settled %.2f (x%.2f) | wave 5: (routed %.2f) past foldReady %.2f, old values folded %.2f, tables + proposal seen %.2f, new values folded %.2f, statistics reduced %.2f | wave 4: published %.2f | next totals complete = step %.2f\n",
+                A(51), A(41), A(42), A(43), A(52), 1.0, A(44) - A(40), A(45), A(46), A(47), A(48), A(49), A(50), A(40));
+        fprintf(stderr, "SWEEP foldReady: stored by wave 0 -> wave 4 / wave 5 past their wait: %.2f / %.2f us; wave 5 still routing when it was stored: %llu steps of %llu, by %.2f us on average\n", A(53), A(54), h[55], h[0], h[55] ? (double)h[56] / (100.0 * (double)h[55]) : 0.0);
+        const double kl = h[55] ? 1.0 / (100.0 * (double)h[55]) : 0.0, ke = (h[0] - h[55]) ? 1.0 / (100.0 * (double)(h[0] - h[55])) : 0.0;
+        fprintf(stderr, "SWEEP late routing steps by the move type of image 0: birth %llu, death %llu, swap %llu, change %llu\n", h[20], h[21], h[22], h[23]);
+        fprintf(stderr, "SWEEP late routing steps: routing took %.2f us, images seen %.2f us after the totals of the step, %llu of them early-verdict steps | other steps: routing took %.2f us, images seen %.2f us after the totals of the PREVIOUS step\n",
+                (double)(long long)h[57] * kl, (double)(long long)h[58] * kl, h[59], (double)(long long)h[60] * ke, (double)(long long)h[61] * ke); }
       fprintf(stderr, "SWEEP folded in, us after the wave's own previous pass: waves 4..7: %.2f %.2f %.2f %.2f\n", h[16] * k, h[17] * k, h[18] * k, h[19] * k);
-      fprintf(stderr, "SWEEP wave 5 (no side jobs), us after its previous pass: images there %.2f, routed %.2f, tables + proposal there %.2f, folded in %.2f, reduced (+ wave 3 published) %.2f\n", h[24] * k, h[25] * k, h[26] * k, h[27] * k, h[28] * k);
+      fprintf(stderr, "SWEEP image wave 1, propose() alone by move type (count, us): birth %llu %.2f, death %llu %.2f, swap %llu %.2f, change %llu %.2f; without a valid move %llu; from the start of the drawing step to propose() %.2f us\n",
+              h[36], h[36] ? h[24] / (100.0 * h[36]) : 0.0, h[37], h[37] ? h[25] / (100.0 * h[37]) : 0.0, h[38], h[38] ? h[26] / (100.0 * h[38]) : 0.0, h[39], h[39] ? h[27] / (100.0 * h[39]) : 0.0, h[62],
+              (h[36] + h[37] + h[38] + h[39]) ? h[63] / (100.0 * (h[36] + h[37] + h[38] + h[39])) : 0.0);
       fprintf(stderr, "SWEEP statistics phase: wave 5 accumulated %.2f, wave-reduced + slots written %.2f, barrier passed %.2f; wave 3 barrier passed %.2f\n", h[30] * k, h[31] * k, h[32] * k, h[33] * k); }
 #endif
     out[0] = cnt ? sum / cnt : 0.0; out[3] = cnt;

@@ -730,12 +730,15 @@ S4B_HD inline void leaf_stats_draws(const TBL& tb, const CA& ca, const ABIN& bin
 }
 
 struct NoHook { S4B_HD void operator()() const {} };
+struct NoHookI { S4B_HD void operator()(int) const {} };
 // `drawsDone` is called once the last random number of the step has been consumed (before the batched leaf arithmetic)
 // `beforeDraws` is called once, before the first random number of the step is drawn (the device uses it to finish loading the generator)
-template <class TR, class TBL, class AF64, class AI32, class ABIN, class CA, class MV, class RNG, class HOOK = NoHook, class HOOK2 = NoHook>
+// `afterAccept(acc)` is called as soon as the accept test is out (acc = 0 also for a proposal without a valid move), before the tree is touched
+template <class TR, class TBL, class AF64, class AI32, class ABIN, class CA, class MV, class RNG, class HOOK = NoHook, class HOOK2 = NoHook, class HOOK3 = NoHookI>
 S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, const MV& m, double sigma, RNG* rng,
                          const Proposal* pr, TBL& tb, const ABIN& binCnt, const ABIN& binSum, const ABIN& binWt, DecideWork<AF64>& wk,
-                         int32_t* accepted, StepRecord* rec, CA& ca, const HOOK& drawsDone = HOOK(), bool keepCache = true, const HOOK2& beforeDraws = HOOK2()) {
+                         int32_t* accepted, StepRecord* rec, CA& ca, const HOOK& drawsDone = HOOK(), bool keepCache = true, const HOOK2& beforeDraws = HOOK2(),
+                         const HOOK3& afterAccept = HOOK3()) {
   TR& pt = tb.prop;
   sigma = S4B_UNI(sigma);
   const double sigma2 = sigma * sigma;
@@ -781,6 +784,7 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
     beforeDraws();
     acc = (r_unif(rng) < S4B_UNI(ratio)) ? 1 : 0;
   } else beforeDraws();
+  afterAccept(acc);
   S4B_DEC_T(3);
   // sufficient statistics of every leaf of the tree we end up with, in DFS order; the uniforms of the leaf
   // draws are consumed in that order, the (expensive) quantile / posterior arithmetic is batched afterwards

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512) void k_sweep(u64* buf, u64* grp, u64* stat, un
 // step - 1 was published by everybody; nobody adds to it before it has seen this workgroup's publish of step + 1, which waits for
 // the clearing stores).
 template <int W>
-__global__ __launch_bounds__(512) void k_sweep_atomic(u64* buf, u64* stat, unsigned* err, int steps, int tPass, int tDec, int C, int strideWords, int pollSleep) {
+__global__ __launch_bounds__(512) void k_sweep_atomic(u64* buf, u64* stat, unsigned* err, int steps, int tPass, int tDec, int C, int strideWords, int pollSleep, int ws) {
   extern __shared__ unsigned char dyn[];
   __shared__ double tot[WMAX];
   __shared__ int arrived, bad;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512) void k_sweep_atomic(u64* buf, u64* stat, unsig
       if (lane < W) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const u64 field = (u64)((st % 1000) * 4 + lane) + (u64)b;
-        __hip_atomic_fetch_add(cur + (size_t)(b % C) * strideWords + lane, field + (1ull << 58), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(cur + (size_t)(b % C) * strideWords + (size_t)lane * ws, field + (1ull << 58), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // poll: C * W words over 64 lanes
       constexpr int PER = (32 * W + 63) / 64;    // up to C = 32 copies
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512) void k_sweep_atomic(u64* buf, u64* stat, unsig
         for (int j = 0; j < PER; ++j) {
           const int e = lane + j * 64; const int c = e / W, k = e % W;
           const bool in = c < C;
-          w[j] = in ? ld_agent(cur + (size_t)c * strideWords + k) : 0ull;
+          w[j] = in ? ld_agent(cur + (size_t)c * strideWords + (size_t)k * ws) : 0ull;
         }
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512) void k_sweep_atomic(u64* buf, u64* stat, unsig
         if (pollSleep == 2) __builtin_amdgcn_s_sleep(2); else if (pollSleep == 8) __builtin_amdgcn_s_sleep(8);
       }
       if (!fine) { bad = 1; *err = 1; }
-      if (b < C && lane < W) st_agent(clr + (size_t)b * strideWords + lane, 0ull);
+      if (b < C && lane < W) st_agent(clr + (size_t)b * strideWords + (size_t)lane * ws, 0ull);
       // totals: word k = sum over copies
       double sums[PER];
 #pragma unroll
@@ -205,21 +205,21 @@ __global__ __launch_bounds__(512) void k_sweep_atomic(u64* buf, u64* stat, unsig
   if (threadIdx.x == 0) stat[b] = tExch;
 }
 template <int W>
-static int run_atomic(u64* buf, u64* stat, unsigned* err, int G, int steps, int tPass, int tDec, int C, int strideWords, int pollSleep) {
+static int run_atomic(u64* buf, u64* stat, unsigned* err, int G, int steps, int tPass, int tDec, int C, int strideWords, int pollSleep, int ws = 1) {
   hipEvent_t e0, e1; OK(hipEventCreate(&e0)); OK(hipEventCreate(&e1));
   OK(hipMemset(buf, 0, (size_t)4 * C * strideWords * 8));
   OK(hipMemset(stat, 0, GMAX * 8)); OK(hipMemset(err, 0, 64));
   OK(hipFuncSetAttribute((const void*)k_sweep_atomic<W>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   OK(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL((k_sweep_atomic<W>), dim3(G), dim3(512), 100 * 1024, 0, buf, stat, err, steps, tPass, tDec, C, strideWords, pollSleep);
+  hipLaunchKernelGGL((k_sweep_atomic<W>), dim3(G), dim3(512), 100 * 1024, 0, buf, stat, err, steps, tPass, tDec, C, strideWords, pollSleep, ws);
   OK(hipGetLastError());
   OK(hipEventRecord(e1, 0)); OK(hipEventSynchronize(e1));
   float ms = 0; OK(hipEventElapsedTime(&ms, e0, e1));
   u64 s[GMAX]; unsigned er; OK(hipMemcpy(s, stat, sizeof s, hipMemcpyDeviceToHost)); OK(hipMemcpy(&er, err, 4, hipMemcpyDeviceToHost));
   double ex = 0, mx = 0; for (int i = 0; i < G; ++i) { ex += (double)s[i]; if ((double)s[i] > mx) mx = (double)s[i]; }
   const double busyUs = (tPass + tDec) / 100.0;
-  printf("variant 2 (integer atomics), W = %2d words, %2d copies, copy stride %5d words, poll sleep %2d, busy %.1f + %.1f us: %.3f us per step = busy + %.3f;  pass-end -> totals in wave 0: mean %.2f, slowest %.2f us;  err %u\n",
-         W, C, strideWords, pollSleep, tPass / 100.0, tDec / 100.0, 1e3 * ms / steps, 1e3 * ms / steps - busyUs, ex / G / steps / 100.0, mx / steps / 100.0, er);
+  printf("variant 2 (integer atomics), W = %2d words, %2d copies, copy stride %5d words, word stride %2d, poll sleep %2d, busy %.1f + %.1f us: %.3f us per step = busy + %.3f;  pass-end -> totals in wave 0: mean %.2f, slowest %.2f us;  err %u\n",
+         W, C, strideWords, ws, pollSleep, tPass / 100.0, tDec / 100.0, 1e3 * ms / steps, 1e3 * ms / steps - busyUs, ex / G / steps / 100.0, mx / steps / 100.0, er);
   return 0;
 }
 
@@ -249,7 +249,18 @@ int main(int argc, char** argv) {
   u64 *buf, *grp, *stat; unsigned* err;
   OK(hipMalloc(&buf, (size_t)8 << 20)); OK(hipMalloc(&grp, (size_t)3 * WMAX * (GMAX / 2) * 8)); OK(hipMalloc(&stat, GMAX * 8)); OK(hipMalloc(&err, 64));
   const int steps = 3000, G = 256;
-  const bool all = argc > 1;
+  const bool all = argc > 1 && argv[1][0] == 'a';
+  if (argc > 1 && argv[1][0] == 'w') {     // words of one copy on separate cache lines (word stride 16 = 128 B, 32 = 256 B)
+    for (int rep = 0; rep < 2; ++rep) for (int busyOn = 0; busyOn < 2; ++busyOn) {
+      const int tp = busyOn ? 230 : 0, td = busyOn ? 400 : 0;
+      for (int C : {4, 8, 16}) for (int ws : {1, 16, 32}) {
+        if (run_atomic<6>(buf, stat, err, G, steps, tp, td, C, 32 * ws + 16, 2, ws)) return 1;
+        if (run_atomic<12>(buf, stat, err, G, steps, tp, td, C, 32 * ws + 16, 2, ws)) return 1;
+        if (run_atomic<24>(buf, stat, err, G, steps, tp, td, C, 32 * ws + 16, 2, ws)) return 1;
+      }
+    }
+    return 0;
+  }
   for (int rep = 0; rep < 2; ++rep) {
     for (int busyOn = 0; busyOn < 2; ++busyOn) {
       const int tp = busyOn ? 230 : 0, td = busyOn ? 400 : 0;
