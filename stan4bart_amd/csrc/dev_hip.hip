@@ -1006,12 +1006,20 @@ __global__ __launch_bounds__(BLOCK) void k_param_mean(BartArrays a, StanArrays s
 // one wave: new scale (when update) + sigma on the rescaled scale; then rescales every leaf value
 __global__ void k_scale(BartArrays a, StanArrays s, int update, int gridUsed) {
   __shared__ ScaleState sh;
+  __shared__ double smn[16], smx[16];
+  if (update) {   // (min / max: any order gives the same result)
+    double mn = INFINITY, mx = -INFINITY;
+    for (int b = threadIdx.x; b < gridUsed; b += blockDim.x) { mn = fmin(mn, s.mmPart[b]); mx = fmax(mx, s.mmPart[a.grid + b]); }
+    for (int o = 32; o; o >>= 1) { mn = fmin(mn, __shfl_xor(mn, o)); mx = fmax(mx, __shfl_xor(mx, o)); }
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     ScaleState sc = *a.scale;
     sc.min0 = sc.min; sc.range0 = sc.range; sc.shiftPerTree = 0.0;
     if (update) {
       double mn = INFINITY, mx = -INFINITY;
-      for (int b = 0; b < gridUsed; ++b) { mn = fmin(mn, s.mmPart[b]); mx = fmax(mx, s.mmPart[a.grid + b]); }
+      for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) { mn = fmin(mn, smn[w]); mx = fmax(mx, smx[w]); }
       sc.min = mn; sc.max = mx; sc.range = mx - mn;
       sc.shiftPerTree = (sc.min0 + 0.5 * sc.range0 - sc.min - 0.5 * sc.range) / (double)a.T;
     }

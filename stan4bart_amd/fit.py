@@ -229,12 +229,25 @@ def make_sampler_args(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_tes
         if np.any(num_normals < 2):
             raise ValueError("product_normal needs df >= 2")
     ss = float(np.std(y, ddof=1)) if not is_binary else 1.0
+    use_qr = bool(stan_args.get("QR", False))
     if prior_dist > 0 and autoscale:
         if not is_binary:
             prior_scale = ss * prior_scale
-        for k in range(K):
+        for k in range(K if not use_qr else 0):          # (reference R/stan4bart_fit.R:218: not with QR)
             xs = 1.0 if len(np.unique(Xc[:, k])) == 1 else float(np.std(Xc[:, k], ddof=1))
             prior_scale[k] = max(1e-12, prior_scale[k] / xs)
+    # stan_args = list(QR = TRUE) (reference R/stan4bart_fit.R:239-258): the sampler sees Q * scale_factor of the thin QR decomposition of
+    # the centred design; the coefficient rows of its draws are mapped back with R_inv in fit_worker (R/stan4bart_fit.R:560-570)
+    R_inv = None
+    xbar_model = xbar
+    if use_qr and K > 0:
+        if K <= 1:
+            raise ValueError("'QR' can only be specified when there are multiple predictors.")
+        Q, Rm = np.linalg.qr(Xc)
+        scale_factor = float(np.sqrt(n - 1.0)) if autoscale else float(Rm[K - 1, K - 1])
+        R_inv = np.linalg.solve(Rm, np.eye(K)) * scale_factor
+        Xc = Q * scale_factor
+        xbar_model = xbar @ R_inv
     prior_scale_for_aux = 0.0 if is_binary else ss * 1.0
 
     terms, p, l, w, v, u, q = make_z_csr(groups, n) if len(groups) else ([], [], [], np.zeros(0), np.zeros(0, np.int32),
@@ -272,7 +285,7 @@ def make_sampler_args(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_tes
         warmup=warmup, iter=iter, verbose=verbose, refresh=refresh,
         offset=offset, offset_type=off_types.index(offset_type),
         bart_offset_init=boi, sigma_init=sigma_init, keep_fits=keep_fits, callback=callback, device=device,
-        extras=dict(xbar=xbar, group_terms=terms),
+        extras=dict(xbar=xbar, xbar_model=xbar_model, R_inv=R_inv, group_terms=terms),
     )
 
 
@@ -290,6 +303,12 @@ def fit_worker(make_sampler: Callable[[SamplerArgs, np.ndarray], Sampler], args:
         sampler.disengage_adaptation()
         results["sample"] = sampler.run(args.iter - args.warmup, False, 0)
         results["par_names"] = sampler.stan_par_names()
+        R_inv = (args.extras or {}).get("R_inv")
+        if R_inv is not None:       # QR = TRUE: coefficient rows back to the scale of the design (reference R/stan4bart_fit.R:560-570)
+            rows = [i for i, nm in enumerate(results["par_names"]) if nm.startswith("beta.")]
+            for ph in ("warmup", "sample"):
+                if ph in results and rows:
+                    results[ph]["stan"][rows, :] = R_inv @ results[ph]["stan"][rows, :]
         results["range.bart"] = sampler.get_bart_data_range()
         if args.keep_trees:
             results["trees"] = sampler.get_trees()
