@@ -1050,6 +1050,35 @@ __global__ __launch_bounds__(BLOCK) void k_rescale(BartArrays a, int update) {
   }
 }
 
+// The Stan -> BART hand-off of an iteration that does not update the response scale (every sampling-phase iteration, most warm-up
+// ones) in ONE pass: k_param_mean + k_set_sigma + k_scale(update = 0) + k_rescale(update = 0) with the coefficients in the kernel
+// arguments (K + q <= 64) — same arithmetic per observation, in the same order, as the four kernels.
+struct OffsetArgs { int32_t fixed, random, addUser, pad; double sigmaData; double par[64]; };
+__global__ __launch_bounds__(BLOCK) void k_offset_rescale(BartArrays a, StanArrays s, OffsetArgs o) {
+  __shared__ double par[64];
+  if (threadIdx.x < 64) par[threadIdx.x] = o.par[threadIdx.x];
+  __syncthreads();
+  const double mn = a.scale->min, range = a.scale->range;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * BLOCK) {
+    double eta = 0.0;
+    if (o.fixed) for (int k = 0; k < s.K; ++k) eta += s.X[(size_t)k * a.n + i] * par[k];
+    if (o.random && s.q) for (int e = s.u[i]; e < s.u[i + 1]; ++e) eta += s.w[e] * par[s.K + s.v[e]];
+    if (o.addUser) eta += a.userOffset[i];
+    a.offNew[i] = eta;
+    const double y = a.y[i];
+    const double yOld = (y - a.off[i] - mn) / range - 0.5;
+    const double F = yOld - a.R[i];
+    const double yNew = (y - eta - mn) / range - 0.5;
+    a.R[i] = yNew - F;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // (min and range keep their values: the other workgroups may read them meanwhile)
+    ScaleState sc = *a.scale;
+    sc.min0 = sc.min; sc.range0 = sc.range; sc.shiftPerTree = 0.0;
+    sc.sigmaData = o.sigmaData; sc.sigma = o.sigmaData / sc.range;
+    *a.scale = sc;
+  }
+}
+
 // probit: latent response z_i ~ N(fit_i + offset_i, 1) truncated to (0, inf) if y_i = 1, (-inf, 0] otherwise
 // (dbarts sampleProbitLatentVariables; reference consumes it through storeLatents, src/init.cpp:289,845).
 // The draws come from R's sequential generator with a data-dependent number of uniforms per observation, so the
@@ -2108,7 +2137,7 @@ class DevHip {
     sync();
   }
   void download_leaf_plane(int t, uint16_t* out) { download(out, a_.leaf + (size_t)t * a_.npad, (size_t)n_); sync(); }
-  void get_scale(ScaleState& s) { download(&s, a_.scale, 1); sync(); }
+  void get_scale(ScaleState& s) { flush_hand_off(); download(&s, a_.scale, 1); sync(); }
   int32_t error_flags() { int32_t e = 0; download(&e, a_.errFlag, 1); sync(); return e; }
   int64_t launches() const { return launches_; }
   void set_trace(bool on) { a_.traceOn = on ? 1 : 0; HIP_OK(hipMemsetAsync(a_.traceCount, 0, 4, stream_)); sync(); }
@@ -2126,17 +2155,45 @@ class DevHip {
     upload(a_.offNew, off, (size_t)n_);
     hipLaunchKernelGGL(k_param_mean, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, 0, 0, 0, 1, a_.offNew); ++launches_;
   }
+  // offset_from_params + set_sigma + rescale(false) of one Gibbs iteration are ONE launch (k_offset_rescale) when the coefficients fit
+  // the kernel arguments: the first two calls are held until rescale() knows whether the scale is updated
   void offset_from_params(const double* beta, const double* b, int fixed, int random, int addUser) {
+    flush_hand_off();
+    if (!binary_ && K_ + q_ <= 64) {
+      pend_.fixed = fixed; pend_.random = random; pend_.addUser = addUser; pend_.pad = 0; pend_.sigmaData = 0.0;
+      for (int k = 0; k < K_; ++k) pend_.par[k] = beta[k];
+      for (int j = 0; j < q_; ++j) pend_.par[K_ + j] = b[j];
+      for (int j = K_ + q_; j < 64; ++j) pend_.par[j] = 0.0;
+      pendOffset_ = true; pendSigma_ = false;
+      return;
+    }
     push_params(beta, b);
     hipLaunchKernelGGL(k_param_mean, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, fixed, random, addUser, 0, a_.offNew); ++launches_;
+  }
+  void flush_hand_off() {    // the held calls as their own kernels
+    if (!pendOffset_) return;
+    pendOffset_ = false;
+    push_params(pend_.par, pend_.par + K_);
+    hipLaunchKernelGGL(k_param_mean, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, pend_.fixed, pend_.random, pend_.addUser, 0, a_.offNew); ++launches_;
+    if (pendSigma_) { pendSigma_ = false; hipLaunchKernelGGL(k_set_sigma, dim3(1), dim3(1), 0, stream_, a_, pend_.sigmaData); ++launches_; }
   }
   void param_mean_to_host(const double* beta, const double* b, double* out) {
     push_params(beta, b);
     hipLaunchKernelGGL(k_param_mean, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, 1, 1, 0, 0, s_.e); ++launches_;
     download(out, s_.e, (size_t)n_); sync();
   }
-  void set_sigma(double s) { hipLaunchKernelGGL(k_set_sigma, dim3(1), dim3(1), 0, stream_, a_, s); ++launches_; }
+  void set_sigma(double s) {
+    if (pendOffset_) { pend_.sigmaData = s; pendSigma_ = true; return; }
+    hipLaunchKernelGGL(k_set_sigma, dim3(1), dim3(1), 0, stream_, a_, s); ++launches_;
+  }
   void rescale(bool update) {
+    if (pendOffset_ && pendSigma_ && !update) {
+      pendOffset_ = false; pendSigma_ = false;
+      hipLaunchKernelGGL(k_offset_rescale, dim3(gridN_), dim3(BLOCK), 0, stream_, a_, s_, pend_); ++launches_;
+      std::swap(a_.off, a_.offNew);
+      return;
+    }
+    flush_hand_off();
     if (binary_) {
       hipLaunchKernelGGL(k_rescale_binary, dim3(gridN_), dim3(BLOCK), 0, stream_, a_); ++launches_;
       std::swap(a_.off, a_.offNew);
@@ -2188,22 +2245,43 @@ class DevHip {
   }
   // persistent path: one k_sweep launch per sweep; the status word (host-visible) says how far it got: T + 1 = the whole sweep,
   // t in 1..T = k_step launches t..T finish it (a tree outgrew the wave-register control path), 0 = nothing done (tree 0 did)
-  void sweep_persistent_one() {
+  void sweep_persistent_launch() {
     HIP_OK(hipMemsetAsync(xbuf_, 0, sizeof(unsigned long long) * (size_t)XC_RING * XC_BUF_WORDS, stream_));
     sweepStatus_[0] = -1;
     hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, SweepArgs{xbuf_, sweepStatusDev_}); ++launches_;
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(stream_));
+  }
+  // the launch has ended (the caller waited for it or for something behind it on the stream): true = the sweep is complete, false = the
+  // rest of it was handed over and has just been queued as k_step launches
+  bool sweep_persistent_finish() {
     const int st = sweepStatus_[0];
     ++sweepCount_;
-    if (st == T_ + 1) return;
+    if (st == T_ + 1) return true;
     if (st < 0 || st > T_ + 1) throw std::runtime_error("persistent tree sweep: the launch did not complete (a workgroup timed out waiting for the others — is the device shared?)");
     ++sweepHandOvers_;
-    if (st == 0) { sweep_fused_one(); return; }
+    if (st == 0) { sweep_fused_one(); return false; }
     for (int t = st; t <= T_; ++t) { launch_step(t); ++launches_; }
     if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_));
+    return false;
+  }
+  void sweep_persistent_one() {
+    sweep_persistent_launch();
+    HIP_OK(hipStreamSynchronize(stream_));
+    sweep_persistent_finish();
+  }
+  // The Gibbs iteration's sweep followed by the Stan block's inputs (sampler_core.hpp run()).  On the persistent path the host does not
+  // wait for the sweep's status word before queueing the Stan kernels: it waits once, for their result, and looks at the status then.
+  // A sweep that was handed over (a tree outgrew the wave-register control path: rare) is finished and the Stan inputs are formed again —
+  // they only read the BART state and overwrite their own outputs.
+  void sweep_and_stan_inputs(int thin, int mode, bool wantTrain, double* cX, double* cZ, double* s0, double* trainOut) {
+    if (path_ != PATH_SWEEP || binary_ || thin < 1) { sweep(thin); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); return; }
+    for (int k = 0; k + 1 < thin; ++k) sweep_persistent_one();
+    sweep_persistent_launch();
+    stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut);
+    if (!sweep_persistent_finish()) stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut);
   }
   void sweep_impl(int thin) {
+    flush_hand_off();
     if (path_ == PATH_SWEEP) {
       for (int k = 0; k < thin; ++k) { sweep_persistent_one(); if (binary_) launch_latents(); }
       return;
@@ -2377,6 +2455,9 @@ class DevHip {
   // were handed over to k_step so far / all persistent sweeps so far (out[4]), out[6] = wall time per sweep without events
   void profile_sweep_persistent(int nSweeps, int thin, double* out) {
     double sum = 0; int cnt = 0;
+#ifdef S4B_SWEEP_TIMING
+    { sync(); unsigned long long drop[96]; sweep_timing_fetch(drop); }     // (only the sweeps profiled here: not the chain's first ones, which rebuild every structure cache)
+#endif
     for (int sIdx = 0; sIdx < nSweeps * thin; ++sIdx) {
       const int64_t ho = sweepHandOvers_;
       HIP_OK(hipMemsetAsync(xbuf_, 0, sizeof(unsigned long long) * (size_t)XC_RING * XC_BUF_WORDS, stream_));
@@ -2399,7 +2480,7 @@ class DevHip {
       if (ho == sweepHandOvers_) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_)); sum += ms * 1000.0; ++cnt; }
     }
 #ifdef S4B_SWEEP_TIMING
-    { unsigned long long h[64]; sweep_timing_fetch(h);
+    { unsigned long long h[96]; sweep_timing_fetch(h);
       const double k = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0;
       fprintf(stderr, "SWEEP workgroup 100 (avg over %llu steps, %.2f bins, %llu routed after the decision) | pass waves, us after the previous publish: totals gathered (wave 3) %.2f; wave 4: images there %.2f, routed %.2f, tables + proposal there %.2f, arithmetic done %.2f; published (wave 3) = step %.2f | decider, us after its previous step: totals seen %.2f, verdict %.2f, tables out %.2f, step end %.2f | image wave 1, us after its previous image: starts drawing %.2f, drawn %.2f\n",
               h[0], h[0] ? (double)h[7] / (double)h[0] : 0.0, h[8], h[1] * k, h[2] * k, h[3] * k, h[4] * k, h[5] * k, h[6] * k, h[9] * k, h[10] * k, h[11] * k, h[12] * k, h[13] * k, h[14] * k);
@@ -2408,11 +2489,17 @@ class DevHip {
         fprintf(stderr, "SWEEP timeline of a step, us after this workgroup saw the totals complete: wave 3's leaf values %.2f | decider: sees totals %.2f, verdict + old values out %.2f, new values out %.2f | proposal settled %.2f (x%.2f) | wave 5: (routed %.2f) past foldReady %.2f, old values folded %.2f, tables + proposal seen %.2f, new values folded %.2f, statistics reduced %.2f | wave 4: published %.2f | next totals complete = step %.2f\n",
                 A(51), A(41), A(42), A(43), A(52), 1.0, A(44) - A(40), A(45), A(46), A(47), A(48), A(49), A(50), A(40));
         fprintf(stderr, "SWEEP foldReady: stored by wave 0 -> wave 4 / wave 5 past their wait: %.2f / %.2f us; wave 5 still routing when it was stored: %llu steps of %llu, by %.2f us on average\n", A(53), A(54), h[55], h[0], h[55] ? (double)h[56] / (100.0 * (double)h[55]) : 0.0);
+        const double kl0 = h[55] ? 1.0 / (100.0 * (double)h[55]) : 0.0;
         const double kl = h[55] ? 1.0 / (100.0 * (double)h[55]) : 0.0, ke = (h[0] - h[55]) ? 1.0 / (100.0 * (double)(h[0] - h[55])) : 0.0;
+        fprintf(stderr, "SWEEP late routing steps: wave 5 waited %.2f us for the images\n", (double)(long long)h[28] * kl0);
         fprintf(stderr, "SWEEP late routing steps by the move type of image 0: birth %llu, death %llu, swap %llu, change %llu\n", h[20], h[21], h[22], h[23]);
         fprintf(stderr, "SWEEP late routing steps: routing took %.2f us, images seen %.2f us after the totals of the step, %llu of them early-verdict steps | other steps: routing took %.2f us, images seen %.2f us after the totals of the PREVIOUS step\n",
                 (double)(long long)h[57] * kl, (double)(long long)h[58] * kl, h[59], (double)(long long)h[60] * ke, (double)(long long)h[61] * ke); }
       fprintf(stderr, "SWEEP folded in, us after the wave's own previous pass: waves 4..7: %.2f %.2f %.2f %.2f\n", h[16] * k, h[17] * k, h[18] * k, h[19] * k);
+      fprintf(stderr, "SWEEP image drawings (both waves) that took more than 8 us from the settled proposal to imgReady: %llu; generator copied %.2f, model + wait for the staged tree %.2f, tree loaded + generator advanced %.2f, propose() %.2f, image stored %.2f us\n",
+              h[15], h[15] ? h[13] / (100.0 * h[15]) : 0.0, h[15] ? h[14] / (100.0 * h[15]) : 0.0, h[15] ? h[29] / (100.0 * h[15]) : 0.0, h[15] ? h[34] / (100.0 * h[15]) : 0.0, h[15] ? h[70] / (100.0 * h[15]) : 0.0);
+      fprintf(stderr, "SWEEP all image drawings (%llu): cache invalid %llu times, generator block renewed %llu times; tree loaded %.2f, cache %.2f, generator opened + advanced %.2f us\n",
+              h[69], h[64], h[65], h[69] ? h[66] / (100.0 * h[69]) : 0.0, h[69] ? h[67] / (100.0 * h[69]) : 0.0, h[69] ? h[68] / (100.0 * h[69]) : 0.0);
       fprintf(stderr, "SWEEP image wave 1, propose() alone by move type (count, us): birth %llu %.2f, death %llu %.2f, swap %llu %.2f, change %llu %.2f; without a valid move %llu; from the start of the drawing step to propose() %.2f us\n",
               h[36], h[36] ? h[24] / (100.0 * h[36]) : 0.0, h[37], h[37] ? h[25] / (100.0 * h[37]) : 0.0, h[38], h[38] ? h[26] / (100.0 * h[38]) : 0.0, h[39], h[39] ? h[27] / (100.0 * h[39]) : 0.0, h[62],
               (h[36] + h[37] + h[38] + h[39]) ? h[63] / (100.0 * (h[36] + h[37] + h[38] + h[39])) : 0.0);
@@ -2502,6 +2589,7 @@ class DevHip {
 
   // ---- Stan inputs
   void stan_inputs(int mode, bool wantTrain, double* cX, double* cZ, double* s0, double* trainOut) {
+    flush_hand_off();
     if (stanFused_) {
       launch_stan_fused(mode, wantTrain ? 1 : 0, false);
       if (!fetch_fused(cX, cZ, s0)) { reduce_pipeline(mode, wantTrain ? 1 : 0, 0); fetch_out(cX, cZ, s0); recentre_scales(cX, cZ, *s0); }
@@ -2736,6 +2824,7 @@ class DevHip {
   enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_SWEEP = 4 };
   bool sweepOk_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
   int64_t sweepCount_ = 0, sweepHandOvers_ = 0;
+  OffsetArgs pend_; bool pendOffset_ = false, pendSigma_ = false;   // Stan -> BART hand-off calls held for the one-launch form (offset_from_params)
   int pathReq_ = 0, path_ = 0, sharing_ = 1;
   double dbgSweepMs_ = 0; int dbgSweeps_ = 0;
   hipGraph_t graph_ = nullptr; hipGraphExec_t graphExec_ = nullptr; int graphTrace_ = -1; bool useGraph_ = true;

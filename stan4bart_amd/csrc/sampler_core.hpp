@@ -296,11 +296,10 @@ class SamplerCore {
         if (timing) { tph[1] += now() - t0; t0 = now(); }
       }
       if (doBart) {
-        dev_.sweep(thin_);
-        if (timing) { tph[2] += now() - t0; t0 = now(); }
         treeUpdates_ += (long)T_ * thin_;
         const bool emit = !lastOnly || iter == numIter - 1;
-        dev_.stan_inputs(stan_mode(), wantTrain && emit, cX_.data(), cZ_.data(), &s0_, (wantTrain && emit) ? train.data() : nullptr);
+        dev_.sweep_and_stan_inputs(thin_, stan_mode(), wantTrain && emit, cX_.data(), cZ_.data(), &s0_, (wantTrain && emit) ? train.data() : nullptr);
+        if (timing) { tph[2] += now() - t0; t0 = now(); }
         if (nTest_ && emit && ((out && out->bart_test) || callback_)) dev_.test_fits(test.data());
         if (out && emit) {
           if (out->bart_sigma) out->bart_sigma[slot] = sigma_;
@@ -317,7 +316,7 @@ class SamplerCore {
       }
       if (keepFits_) ++slot;
     }
-    if (timing) std::fprintf(stderr, "S4B host ms/iter: nuts %.3f  offset+rescale issue %.3f  sweep issue %.3f  stan_inputs+wait %.3f\n",
+    if (timing) std::fprintf(stderr, "S4B host ms/iter: nuts %.3f  offset+rescale issue %.3f  sweep + stan inputs (wait) %.3f  results %.3f\n",
                              1e3 * tph[0] / numIter, 1e3 * tph[1] / numIter, 1e3 * tph[2] / numIter, 1e3 * tph[3] / numIter);
     check_device();
   }

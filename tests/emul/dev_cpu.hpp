@@ -260,6 +260,9 @@ class DevCpu {
   }
 
   // ---- Stan inputs
+  void sweep_and_stan_inputs(int thin, int mode, bool wantTrain, double* cX, double* cZ, double* s0, double* trainOut) {
+    sweep(thin); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut);
+  }
   void stan_inputs(int mode, bool wantTrain, double* cX, double* cZ, double* s0, double* trainOut) {
     double ss = 0.0;
     for (int k = 0; k < K_; ++k) cX[k] = 0.0;
