@@ -2021,7 +2021,7 @@ class DevHip {
         sweepOk_ = fusedOk_ && d.weights == nullptr && nQuads <= (int64_t)(a.gridF - 1) * SW_PT * SW_PF && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount &&
                    sweep_lds_bytes() + 40 * 1024 <= 160 * 1024;
         if (sweepOk_) {
-          xbuf_ = zalloc<unsigned long long>((size_t)XC_RING * XC_BUF_WORDS);
+          xbuf_ = zalloc<unsigned long long>((size_t)2 * XC_RING * XC_BUF_WORDS);   // two rings: a launch uses one and clears the other for the next launch
           HIP_OK(hipHostMalloc(&sweepStatus_, 64, hipHostMallocCoherent | hipHostMallocMapped));
           sweepStatus_[0] = -1;
           { void* dp = nullptr; HIP_OK(hipHostGetDevicePointer(&dp, sweepStatus_, 0)); sweepStatusDev_ = (int32_t*)dp; }
@@ -2246,10 +2246,15 @@ class DevHip {
   // persistent path: one k_sweep launch per sweep; the status word (host-visible) says how far it got: T + 1 = the whole sweep,
   // t in 1..T = k_step launches t..T finish it (a tree outgrew the wave-register control path), 0 = nothing done (tree 0 did)
   void sweep_persistent_launch() {
-    HIP_OK(hipMemsetAsync(xbuf_, 0, sizeof(unsigned long long) * (size_t)XC_RING * XC_BUF_WORDS, stream_));
     sweepStatus_[0] = -1;
-    hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, SweepArgs{xbuf_, sweepStatusDev_}); ++launches_;
+    hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
     HIP_OK(hipGetLastError());
+  }
+  SweepArgs sweep_args() {     // (the exchange ring of this launch, the one it clears for the next launch)
+    unsigned long long* cur = xbuf_ + (size_t)xbufParity_ * XC_RING * XC_BUF_WORDS;
+    unsigned long long* nxt = xbuf_ + (size_t)(1 - xbufParity_) * XC_RING * XC_BUF_WORDS;
+    xbufParity_ ^= 1;
+    return SweepArgs{cur, sweepStatusDev_, nxt};
   }
   // the launch has ended (the caller waited for it or for something behind it on the stream): true = the sweep is complete, false = the
   // rest of it was handed over and has just been queued as k_step launches
@@ -2460,10 +2465,9 @@ class DevHip {
 #endif
     for (int sIdx = 0; sIdx < nSweeps * thin; ++sIdx) {
       const int64_t ho = sweepHandOvers_;
-      HIP_OK(hipMemsetAsync(xbuf_, 0, sizeof(unsigned long long) * (size_t)XC_RING * XC_BUF_WORDS, stream_));
       HIP_OK(hipEventRecord(evStart_, stream_));
       sweepStatus_[0] = -1;
-      hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, SweepArgs{xbuf_, sweepStatusDev_}); ++launches_;
+      hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
       HIP_OK(hipEventRecord(evStop_, stream_));
       sync();
       const int st = sweepStatus_[0];
@@ -2824,6 +2828,7 @@ class DevHip {
   enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_SWEEP = 4 };
   bool sweepOk_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
   int64_t sweepCount_ = 0, sweepHandOvers_ = 0;
+  int xbufParity_ = 0;
   OffsetArgs pend_; bool pendOffset_ = false, pendSigma_ = false;   // Stan -> BART hand-off calls held for the one-launch form (offset_from_params)
   int pathReq_ = 0, path_ = 0, sharing_ = 1;
   double dbgSweepMs_ = 0; int dbgSweeps_ = 0;
