@@ -26,11 +26,15 @@
 namespace s4b {
 
 // ---------------------------------------------------------------- reverse-mode tape
+// The model's control flow depends on the data description only (StanSpec), never on parameter values: the tape of a gradient has
+// the same nodes in the same order every time.  Every node therefore carries its operation, and once recorded a tape is REPLAYED —
+// values and partial derivatives recomputed in place, node by node, with the formulas that recorded them — instead of being rebuilt
+// through the model code (hundreds of gradients per Gibbs iteration once the chain runs deep NUTS trees).
+enum TapeCode : int { T_CONST = 0, T_INPUT, T_ADD, T_SUB, T_MUL, T_DIV, T_ADDC, T_SUBC, T_MULC, T_DIVC, T_CSUB, T_CDIV, T_SQRT, T_EXP, T_LOG,
+                      T_SQUARE, T_LOG1M, T_STDNORMAL, T_INVLOGIT, T_INVLOGIT_LOGJAC };
 class Tape {
  public:
-  struct Op { double val; int a, b; double da, db; };
-  // flat storage with an explicit fill count: recording a node is a bounds check and one store (the tape is re-recorded
-  // for every gradient, a few hundred nodes, hundreds of gradients per Gibbs iteration)
+  struct Op { double val; int a, b; double da, db; double c; int code; int k; };
   struct Ops {
     std::vector<Op> buf; size_t n = 0;
     size_t size() const { return n; }
@@ -42,10 +46,49 @@ class Tape {
   } ops;
   std::vector<double> adj;
   void clear() { ops.clear(); }
-  int leaf(double v) { return ops.push({v, -1, -1, 0, 0}); }
-  int un(int a, double v, double da) { return ops.push({v, a, -1, da, 0}); }
-  int bin(int a, int b, double v, double da, double db) { return ops.push({v, a, b, da, db}); }
+  // value and partial derivatives of one node from its operands
+  static inline void eval(Op& o, const Op* all) {
+    const double x = o.a >= 0 ? all[o.a].val : 0.0, y = o.b >= 0 ? all[o.b].val : 0.0, c = o.c;
+    switch (o.code) {
+      case T_CONST: case T_INPUT: break;
+      case T_ADD: o.val = x + y; o.da = 1; o.db = 1; break;
+      case T_SUB: o.val = x - y; o.da = 1; o.db = -1; break;
+      case T_MUL: o.val = x * y; o.da = y; o.db = x; break;
+      case T_DIV: { const double r = x / y; o.val = r; o.da = 1.0 / y; o.db = -r / y; break; }
+      case T_ADDC: o.val = x + c; o.da = 1; break;
+      case T_SUBC: o.val = x - c; o.da = 1; break;
+      case T_MULC: o.val = x * c; o.da = c; break;
+      case T_DIVC: o.val = x / c; o.da = 1.0 / c; break;
+      case T_CSUB: o.val = c - x; o.da = -1; break;
+      case T_CDIV: { const double r = c / x; o.val = r; o.da = -r / x; break; }
+      case T_SQRT: { const double r = std::sqrt(x); o.val = r; o.da = 0.5 / r; break; }
+      case T_EXP: { const double e = std::exp(x); o.val = e; o.da = e; break; }
+      case T_LOG: o.val = std::log(x); o.da = 1.0 / x; break;
+      case T_SQUARE: o.val = x * x; o.da = 2 * x; break;
+      case T_LOG1M: o.val = std::log1p(-x); o.da = -1.0 / (1.0 - x); break;
+      case T_STDNORMAL: o.val = -0.5 * x * x - 0.91893853320467274178; o.da = -x; break;
+      case T_INVLOGIT: { const double il = 1.0 / (1.0 + std::exp(-x)); o.val = il; o.da = il * (1.0 - il); break; }
+      case T_INVLOGIT_LOGJAC: {   // log-Jacobian of lub_constrain(x, 0, 1): -|x| - 2 log1p(exp(-|x|))
+        const double ax = std::fabs(x), sg = x >= 0 ? 1.0 : -1.0, e = std::exp(-ax);
+        o.val = -ax - 2.0 * std::log1p(e); o.da = -sg + 2.0 * sg * e / (1.0 + e); break;
+      }
+    }
+  }
+  int node(int code, int a, int b, double c) {
+    Op o; o.val = 0; o.a = a; o.b = b; o.da = 0; o.db = 0; o.c = c; o.code = code; o.k = -1;
+    const int i = ops.push(o);
+    eval(ops[(size_t)i], ops.buf.data());
+    return i;
+  }
+  int leaf(double v) { Op o; o.val = v; o.a = -1; o.b = -1; o.da = 0; o.db = 0; o.c = 0; o.code = T_CONST; o.k = -1; return ops.push(o); }
+  int input(int k, double v) { Op o; o.val = v; o.a = -1; o.b = -1; o.da = 0; o.db = 0; o.c = 0; o.code = T_INPUT; o.k = k; return ops.push(o); }
   double val(int i) const { return ops[(size_t)i].val; }
+  // the recorded nodes again, for new input values (the caller has stored them in the input nodes)
+  void replay() {
+    Op* const all = ops.buf.data();
+    const size_t n = ops.size();
+    for (size_t i = 0; i < n; ++i) if (all[i].code > T_INPUT) eval(all[i], all);
+  }
   // propagate: caller seeds adj (size = ops.size()) then calls backward()
   void backward() {
     for (int i = (int)ops.size() - 1; i >= 0; --i) {
@@ -62,24 +105,24 @@ struct TV {   // tape variable handle
   Tape* t; int i;
   double v() const { return t->val(i); }
 };
-inline TV operator+(TV a, TV b) { return {a.t, a.t->bin(a.i, b.i, a.v() + b.v(), 1, 1)}; }
-inline TV operator-(TV a, TV b) { return {a.t, a.t->bin(a.i, b.i, a.v() - b.v(), 1, -1)}; }
-inline TV operator*(TV a, TV b) { return {a.t, a.t->bin(a.i, b.i, a.v() * b.v(), b.v(), a.v())}; }
-inline TV operator/(TV a, TV b) { double r = a.v() / b.v(); return {a.t, a.t->bin(a.i, b.i, r, 1.0 / b.v(), -r / b.v())}; }
-inline TV operator+(TV a, double c) { return {a.t, a.t->un(a.i, a.v() + c, 1)}; }
-inline TV operator-(TV a, double c) { return {a.t, a.t->un(a.i, a.v() - c, 1)}; }
-inline TV operator*(TV a, double c) { return {a.t, a.t->un(a.i, a.v() * c, c)}; }
+inline TV operator+(TV a, TV b) { return {a.t, a.t->node(T_ADD, a.i, b.i, 0)}; }
+inline TV operator-(TV a, TV b) { return {a.t, a.t->node(T_SUB, a.i, b.i, 0)}; }
+inline TV operator*(TV a, TV b) { return {a.t, a.t->node(T_MUL, a.i, b.i, 0)}; }
+inline TV operator/(TV a, TV b) { return {a.t, a.t->node(T_DIV, a.i, b.i, 0)}; }
+inline TV operator+(TV a, double c) { return {a.t, a.t->node(T_ADDC, a.i, -1, c)}; }
+inline TV operator-(TV a, double c) { return {a.t, a.t->node(T_SUBC, a.i, -1, c)}; }
+inline TV operator*(TV a, double c) { return {a.t, a.t->node(T_MULC, a.i, -1, c)}; }
 inline TV operator*(double c, TV a) { return a * c; }
-inline TV operator/(TV a, double c) { return {a.t, a.t->un(a.i, a.v() / c, 1.0 / c)}; }
-inline TV operator-(double c, TV a) { return {a.t, a.t->un(a.i, c - a.v(), -1)}; }
-inline TV operator/(double c, TV a) { double r = c / a.v(); return {a.t, a.t->un(a.i, r, -r / a.v())}; }
-inline TV tsqrt(TV a) { double s = std::sqrt(a.v()); return {a.t, a.t->un(a.i, s, 0.5 / s)}; }
-inline TV texp(TV a) { double e = std::exp(a.v()); return {a.t, a.t->un(a.i, e, e)}; }
-inline TV tlog(TV a) { return {a.t, a.t->un(a.i, std::log(a.v()), 1.0 / a.v())}; }
-inline TV tsquare(TV a) { return {a.t, a.t->un(a.i, a.v() * a.v(), 2 * a.v())}; }
-inline TV tlog1m(TV a) { return {a.t, a.t->un(a.i, std::log1p(-a.v()), -1.0 / (1.0 - a.v()))}; }
+inline TV operator/(TV a, double c) { return {a.t, a.t->node(T_DIVC, a.i, -1, c)}; }
+inline TV operator-(double c, TV a) { return {a.t, a.t->node(T_CSUB, a.i, -1, c)}; }
+inline TV operator/(double c, TV a) { return {a.t, a.t->node(T_CDIV, a.i, -1, c)}; }
+inline TV tsqrt(TV a) { return {a.t, a.t->node(T_SQRT, a.i, -1, 0)}; }
+inline TV texp(TV a) { return {a.t, a.t->node(T_EXP, a.i, -1, 0)}; }
+inline TV tlog(TV a) { return {a.t, a.t->node(T_LOG, a.i, -1, 0)}; }
+inline TV tsquare(TV a) { return {a.t, a.t->node(T_SQUARE, a.i, -1, 0)}; }
+inline TV tlog1m(TV a) { return {a.t, a.t->node(T_LOG1M, a.i, -1, 0)}; }
 // log N(z | 0, 1) as one node
-inline TV tstd_normal_lpdf(TV z) { return {z.t, z.t->un(z.i, -0.5 * z.v() * z.v() - 0.91893853320467274178, -z.v())}; }
+inline TV tstd_normal_lpdf(TV z) { return {z.t, z.t->node(T_STDNORMAL, z.i, -1, 0)}; }
 
 // ---------------------------------------------------------------- model description (the stanData list)
 struct StanSpec {
@@ -132,7 +175,7 @@ class HostModel {
     tp.clear();
     tp.ops.reserve(4096);
     qidx.resize((size_t)sp.D);
-    for (int i = 0; i < sp.D; ++i) qidx[(size_t)i] = tp.leaf(qv[(size_t)i]);
+    for (int i = 0; i < sp.D; ++i) qidx[(size_t)i] = tp.input(i, qv[(size_t)i]);
     auto Q = [&](int i) { return TV{&tp, qidx[(size_t)i]}; };
     TV lp{&tp, tp.leaf(0.0)};
     int pos = 0;
@@ -154,12 +197,8 @@ class HostModel {
     for (int j = 0; j < sp.len_z_T; ++j) z_T.push_back(Q(pos++));
     for (int j = 0; j < sp.len_rho; ++j) {   // lub_constrain(x, 0, 1): inv_logit, log-Jacobian -|x| - 2 log1p(exp(-|x|))
       TV x = Q(pos++);
-      double il = 1.0 / (1.0 + std::exp(-x.v()));
-      rho.push_back(TV{&tp, tp.un(x.i, il, il * (1.0 - il))});
-      if (jacobian) {
-        double ax = std::fabs(x.v()), sg = x.v() >= 0 ? 1.0 : -1.0, e = std::exp(-ax);
-        lp = lp + TV{&tp, tp.un(x.i, -ax - 2.0 * std::log1p(e), -sg + 2.0 * sg * e / (1.0 + e))};
-      }
+      rho.push_back(TV{&tp, tp.node(T_INVLOGIT, x.i, -1, 0)});
+      if (jacobian) lp = lp + TV{&tp, tp.node(T_INVLOGIT_LOGJAC, x.i, -1, 0)};
     }
     auto lb0 = [&](int idx) { TV x = Q(idx); if (jacobian) lp = lp + x; return texp(x); };
     for (int j = 0; j < sp.len_conc; ++j) zeta.push_back(lb0(pos++));
@@ -279,7 +318,10 @@ class HostModel {
 #ifdef S4B_NUTS_TIMING
     const auto t0 = std::chrono::steady_clock::now();
 #endif
-    forward(tape_, qv, F, qidx, true);
+    if (tapeHoldsGradient_) {      // same nodes as last time: new inputs, values and partials recomputed in place
+      for (int i = 0; i < sp.D; ++i) tape_.ops[(size_t)qidx[(size_t)i]].val = qv[(size_t)i];
+      tape_.replay();
+    } else { forward(tape_, qv, F, qidx, true); tapeHoldsGradient_ = true; }
 #ifdef S4B_NUTS_TIMING
     const auto t1 = std::chrono::steady_clock::now();
 #endif
@@ -314,6 +356,7 @@ class HostModel {
   void write_array(const std::vector<double>& qv, double* out) {
     Fwd F; std::vector<int> qidx;
     F.wantConstrained = true;
+    tapeHoldsGradient_ = false;      // (this recording replaces the gradient's nodes)
     forward(tape_, qv, F, qidx, false);
     int o = 0;
     for (auto& x : F.constrained) out[o++] = x.v();
@@ -337,7 +380,7 @@ class HostModel {
 #ifdef S4B_NUTS_TIMING
   double tFwd_ = 0, tLik_ = 0, tBwd_ = 0;
 #endif
-  Tape tape_;
+  Tape tape_; bool tapeHoldsGradient_ = false;
   mutable std::vector<TV> w_[6];
   Fwd fwd_; std::vector<int> qidx_; std::vector<double> bufBeta_, bufB_, bufGX_, bufGZ_;
   static TV cornish_fisher(TV z, double df) {
@@ -634,6 +677,20 @@ class Nuts {
 
   struct Acc { int n_leapfrog = 0; double sum_metro = 0; };
 
+  // work space of one recursion level of subtree(): allocated once (a level is never active twice at the same time), so that a leapfrog
+  // costs no heap traffic — hundreds of them per Gibbs iteration once the chain runs deep trees
+  struct Level { V p_init_end, sharp_init_end, rho_init, p_final_beg, sharp_final_beg, rho_final, rho_sub, tmp; Pt propose_final; };
+  std::vector<Level> lv_;
+  void ensure_levels() {
+    if ((int)lv_.size() == max_depth_ + 1) return;
+    lv_.resize((size_t)max_depth_ + 1);
+    for (Level& l : lv_) {
+      for (V* v : {&l.p_init_end, &l.sharp_init_end, &l.rho_init, &l.p_final_beg, &l.sharp_final_beg, &l.rho_final, &l.rho_sub, &l.tmp,
+                   &l.propose_final.q, &l.propose_final.p, &l.propose_final.g}) v->assign((size_t)D_, 0.0);
+    }
+  }
+  static void vadd(const V& a, const V& b, V& r) { for (size_t i = 0; i < a.size(); ++i) r[i] = a[i] + b[i]; }
+
   bool subtree(int depth, Pt& propose, V& sharp_beg, V& sharp_end, V& rho, V& p_beg, V& p_end, double H0, double sign,
                double& lsw, Acc& acc) {
     const double ninf = -std::numeric_limits<double>::infinity();
@@ -645,27 +702,32 @@ class Nuts {
       lsw = lse(lsw, H0 - h);
       acc.sum_metro += (H0 - h > 0) ? 1.0 : std::exp(H0 - h);
       propose = z_;
-      sharp_beg = sharp(); sharp_end = sharp_beg;
+      sharp_beg.resize((size_t)D_);
+      for (int i = 0; i < D_; ++i) sharp_beg[(size_t)i] = inv_metric_[(size_t)i] * z_.p[(size_t)i];
+      sharp_end = sharp_beg;
       for (int i = 0; i < D_; ++i) rho[(size_t)i] += z_.p[(size_t)i];
       p_beg = z_.p; p_end = p_beg;
       return !divergent_;
     }
+    Level& L = lv_[(size_t)depth];
     double lsw_init = ninf;
-    V p_init_end((size_t)D_), sharp_init_end((size_t)D_), rho_init((size_t)D_, 0.0);
-    if (!subtree(depth - 1, propose, sharp_beg, sharp_init_end, rho_init, p_beg, p_init_end, H0, sign, lsw_init, acc)) return false;
-    Pt propose_final = z_;
+    std::fill(L.rho_init.begin(), L.rho_init.end(), 0.0);
+    if (!subtree(depth - 1, propose, sharp_beg, L.sharp_init_end, L.rho_init, p_beg, L.p_init_end, H0, sign, lsw_init, acc)) return false;
+    L.propose_final = z_;
     double lsw_final = ninf;
-    V p_final_beg((size_t)D_), sharp_final_beg((size_t)D_), rho_final((size_t)D_, 0.0);
-    if (!subtree(depth - 1, propose_final, sharp_final_beg, sharp_end, rho_final, p_final_beg, p_end, H0, sign, lsw_final, acc)) return false;
+    std::fill(L.rho_final.begin(), L.rho_final.end(), 0.0);
+    if (!subtree(depth - 1, L.propose_final, L.sharp_final_beg, sharp_end, L.rho_final, L.p_final_beg, p_end, H0, sign, lsw_final, acc)) return false;
     double lsw_sub = lse(lsw_init, lsw_final);
     lsw = lse(lsw, lsw_sub);
-    if (lsw_final > lsw_sub) propose = propose_final;
-    else if (rng_.u01() < std::exp(lsw_final - lsw_sub)) propose = propose_final;
-    V rho_sub = vsum(rho_init, rho_final);
-    for (int i = 0; i < D_; ++i) rho[(size_t)i] += rho_sub[(size_t)i];
-    bool ok = uturn_ok(sharp_beg, sharp_end, rho_sub);
-    ok &= uturn_ok(sharp_beg, sharp_final_beg, vsum(rho_init, p_final_beg));
-    ok &= uturn_ok(sharp_init_end, sharp_end, vsum(rho_final, p_init_end));
+    if (lsw_final > lsw_sub) propose = L.propose_final;
+    else if (rng_.u01() < std::exp(lsw_final - lsw_sub)) propose = L.propose_final;
+    vadd(L.rho_init, L.rho_final, L.rho_sub);
+    for (int i = 0; i < D_; ++i) rho[(size_t)i] += L.rho_sub[(size_t)i];
+    bool ok = uturn_ok(sharp_beg, sharp_end, L.rho_sub);
+    vadd(L.rho_init, L.p_final_beg, L.tmp);
+    ok &= uturn_ok(sharp_beg, L.sharp_final_beg, L.tmp);
+    vadd(L.rho_final, L.p_init_end, L.tmp);
+    ok &= uturn_ok(L.sharp_init_end, sharp_end, L.tmp);
     return ok;
   }
 
@@ -673,6 +735,7 @@ class Nuts {
     const double ninf = -std::numeric_limits<double>::infinity();
     eps_ = nom_eps_;
     if (jitter_) eps_ *= 1.0 + jitter_ * (2.0 * rng_.u01() - 1.0);
+    ensure_levels();
     z_.q = cont_;
     draw_momentum(); grad();
     Pt fwd = z_, bck = z_, sample = z_, propose = z_;
