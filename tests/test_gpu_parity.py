@@ -385,3 +385,21 @@ def test_split_probs_and_quantile_cuts(oracle_lib, hip_lib, name, kw, path):
     assert b["tree_path"][0] == path
     assert_chain_parity(a, b, stan=joint)
     assert b["tree_path"][1] == ("two-kernel" if "split.probs" in kw["bart_args"] else path)
+
+
+@pytest.mark.parametrize("hmc_mode", [0, 1])
+def test_handed_over_sweeps_in_a_joint_chain(oracle_lib, hip_lib, hmc_mode):
+    """The host queues the Stan inputs behind k_sweep without waiting for its status word (sweep_and_stan_inputs); a sweep that ends early —
+    a tree outgrew the wave-register control path — is finished with k_step launches and the inputs are formed again.  Trees drawn from a
+    deep prior in a joint chain: sweeps are handed over, and the Stan block still sees the finished sweep."""
+    kw = dict(n=4000, T=2, warmup=5, iter=11, ranef=True, bart_args={"base": 0.99, "power": 0.25, "k": 0.3})
+    args, _ = friedman_case(stan_args={"hmc_mode": hmc_mode}, **kw)
+    oargs, _ = friedman_case(**kw)
+    args.node_capacity = oargs.node_capacity = 1024
+    a = run_chain(oracle_lib, "orc_", oargs)
+    assert a["trace"][:, 4].max() > 32
+    b = run_chain(hip_lib, "s4b_", args, tree_path="persistent")
+    assert b["tree_path"][1] == "persistent"
+    sweeps, handed_over = b["sweep_stats"]
+    assert sweeps == 12 and handed_over > 0, b["sweep_stats"]
+    assert_chain_parity(a, b)
