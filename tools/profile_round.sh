@@ -15,9 +15,12 @@ cd /tmp && export TMPDIR=/tmp
 newest_db() { find "$1" -name '*_results.db' -printf '%T@ %p\n' 2>/dev/null | sort -n | tail -1 | cut -d' ' -f2-; }
 TRAFFIC="{\"_note\": \"$TAG: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python3 bench.py --n N --steps 2 --warmup 1 --profile-sweeps 1, summarised by tools/pmc_traffic.py; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)\""
 for N in 1000000 10000000; do
-  COMMON="--n $N --no-cpu-baseline --no-extra-configs --no-hmc-mode1 --target-n 0 --burn-in 30"
+  # (the kernel trace at n = 1e6 is taken from the benchmark's own chain — 150 warm-up iterations first: a cold chain accepts more moves
+  # and its sweeps are ~8 % longer; the counter passes and n = 1e7 use a short burn-in)
+  COMMON="--n $N --no-cpu-baseline --no-extra-configs --no-hmc-mode1 --target-n 0 --mode-iters 0 --burn-in 30"
+  TRACEBURN=30; [ "$N" = "1000000" ] && TRACEBURN=150
   rm -rf "$OUT/prof_n$N" "$OUT/pmc_fetch_n$N" "$OUT/pmc_write_n$N"
-  timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_n$N" -- python3 "$ROOT/bench.py" $COMMON --steps 5 --warmup 1 > "$OUT/bench_prof_n$N.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_n$N" -- python3 "$ROOT/bench.py" $COMMON --burn-in $TRACEBURN --steps 20 --warmup 5 > "$OUT/bench_prof_n$N.log" 2>&1
   python3 "$ROOT/tools/rocpd_summary.py" "$(newest_db "$OUT/prof_n$N")" "$ROOT/profiles/${TAG}_rocprofv3_prof_n$N.txt"
   timeout 600 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch_n$N" -- python3 "$ROOT/bench.py" $COMMON --steps 2 --warmup 1 --profile-sweeps 1 > "$OUT/pmc_fetch_n$N.log" 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write_n$N" -- python3 "$ROOT/bench.py" $COMMON --steps 2 --warmup 1 --profile-sweeps 1 > "$OUT/pmc_write_n$N.log" 2>&1
@@ -29,7 +32,7 @@ done
 echo "$TRAFFIC}" > "$ROOT/profiles/pmc_traffic.json"
 # the fused launch per tree (k_step: the automatic choice of rounds 2-3, now the hand-over target of the persistent sweep): per-kernel durations
 rm -rf "$OUT/prof_fused"
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_fused" -- python3 "$ROOT/bench.py" --n 1000000 --no-cpu-baseline --no-extra-configs --target-n 0 --no-hmc-mode1 --burn-in 30 --steps 5 --warmup 1 --tree-path fused > "$OUT/bench_prof_fused.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_fused" -- python3 "$ROOT/bench.py" --n 1000000 --no-cpu-baseline --no-extra-configs --target-n 0 --no-hmc-mode1 --mode-iters 0 --burn-in 150 --steps 20 --warmup 5 --tree-path fused > "$OUT/bench_prof_fused.log" 2>&1
 python3 "$ROOT/tools/rocpd_summary.py" "$(newest_db "$OUT/prof_fused")" "$ROOT/profiles/${TAG}_rocprofv3_prof_fused_n1000000.txt"
 # the box's repository copy is scratch: hand the summaries back through gpurun_out/
 mkdir -p "$OUT/profiles" && cp "$ROOT"/profiles/${TAG}_rocprofv3_* "$ROOT/profiles/pmc_traffic.json" "$OUT/profiles/"
