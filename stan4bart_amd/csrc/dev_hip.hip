@@ -520,13 +520,21 @@ struct ControlShared {
   int arrived, verdict;
   long long tPost, tStart0;
 };
-__device__ __forceinline__ void spin_until(int* flag, int target, int32_t* errFlag) {
+#ifdef S4B_TUNING
+__device__ int g_dbgSpin[4];      // (development) who waits for more than ~30 ms: source line, flag value | target << 16, block, thread
+#endif
+__device__ __forceinline__ void spin_until_at(int* flag, int target, int32_t* errFlag, int line) {
   int guard = 0;
   while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
     __builtin_amdgcn_s_sleep(1);
+#ifdef S4B_TUNING
+    if (guard == (1 << 18) && (threadIdx.x & 63) == 0) { g_dbgSpin[0] = line; g_dbgSpin[1] = *flag | (target << 16); g_dbgSpin[2] = (int)blockIdx.x; g_dbgSpin[3] = (int)threadIdx.x; }
+#endif
     if (++guard > (1 << 24)) { *errFlag |= S4B_ERR_INTERNAL; break; }   // never hang the device on a logic error
   }
+  (void)line;
 }
+#define spin_until(flag, target, errFlag) spin_until_at(flag, target, errFlag, __LINE__)
 __device__ __forceinline__ void rng_advance(WaveRng* r, int k) {
   int total = r->mti + k;
   while (total > 624) { mt_regenerate_wave(r->st); total -= 624; r->regen = 1; }
@@ -2246,6 +2254,7 @@ class DevHip {
   // persistent path: one k_sweep launch per sweep; the status word (host-visible) says how far it got: T + 1 = the whole sweep,
   // t in 1..T = k_step launches t..T finish it (a tree outgrew the wave-register control path), 0 = nothing done (tree 0 did)
   void sweep_persistent_launch() {
+    for (int i = 0; i < 16; ++i) sweepStatus_[i] = 0;
     sweepStatus_[0] = -1;
     hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
     HIP_OK(hipGetLastError());
@@ -2262,7 +2271,15 @@ class DevHip {
     const int st = sweepStatus_[0];
     ++sweepCount_;
     if (st == T_ + 1) return true;
-    if (st < 0 || st > T_ + 1) throw std::runtime_error("persistent tree sweep: the launch did not complete (a workgroup timed out waiting for the others — is the device shared?)");
+    if (st < 0 || st > T_ + 1) {
+      int32_t e = 0; (void)hipMemcpy(&e, a_.errFlag, 4, hipMemcpyDeviceToHost);
+      throw std::runtime_error("persistent tree sweep: the launch did not complete (a workgroup timed out waiting for the others — is the device shared?); status " +
+                               std::to_string(st) + ", device error word " + std::to_string(e) + ", first wait that gave up: dev_sweep.inc:" + std::to_string(sweepStatus_[1])
+#ifdef S4B_TUNING
+                               + " | per workgroup (needBig << 24 | paGo << 8 | bailStep): " + std::to_string(sweepStatus_[2]) + " " + std::to_string(sweepStatus_[3]) + " " + std::to_string(sweepStatus_[4]) + " grid " + std::to_string(a_.gridF) + " tickets " + std::to_string(sweepStatus_[8]) + " " + std::to_string(sweepStatus_[9]) + " tail stage " + std::to_string(sweepStatus_[12])
+#endif
+                               );
+    }
     ++sweepHandOvers_;
     if (st == 0) { sweep_fused_one(); return false; }
     for (int t = st; t <= T_; ++t) { launch_step(t); ++launches_; }
@@ -2336,7 +2353,28 @@ class DevHip {
   // one-workgroup launch that handles an oversized first tree
   void sweep_fused_one() {
     hipLaunchKernelGGL(k_step_pre, dim3(1), dim3(FBLOCK), 0, stream_, a_); ++launches_;
-    for (int t = 0; t <= T_; ++t) { launch_step(t); ++launches_; }
+    for (int t = 0; t <= T_; ++t) {
+      launch_step(t); ++launches_;
+#ifdef S4B_TUNING
+      if (getenv("S4B_DEBUG_STEPS")) {      // (development: which launch of the sweep does not come back)
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hipStreamQuery(stream_) != hipSuccess)
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 3.0) {
+            int32_t hw = 0; hipStream_t s2; (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+            (void)hipMemcpyFromSymbolAsync(&hw, HIP_SYMBOL(g_dbgMark), 4, 0, hipMemcpyDeviceToHost, s2); (void)hipStreamSynchronize(s2);
+            { int sp[4] = {0, 0, 0, 0}; (void)hipMemcpyFromSymbolAsync(sp, HIP_SYMBOL(g_dbgSpin), 16, 0, hipMemcpyDeviceToHost, s2); (void)hipStreamSynchronize(s2);
+              fprintf(stderr, "S4B_DEBUG_STEPS: a wave waits at source line %d: flag %d, target %d, block %d, thread %d\n", sp[0], sp[1] & 0xffff, sp[1] >> 16, sp[2], sp[3]); }
+            { std::vector<int> pg(640 * 8); (void)hipMemcpyFromSymbolAsync(pg.data(), HIP_SYMBOL(g_prog), pg.size() * 4, 0, hipMemcpyDeviceToHost, s2); (void)hipStreamSynchronize(s2);
+              int hist[16] = {0}; for (int b = 0; b < a_.gridF; ++b) for (int w = 0; w < 8; ++w) { const int v = pg[(size_t)b * 8 + w]; if ((v >> 8) == t) ++hist[v & 15]; else ++hist[0]; }
+              fprintf(stderr, "S4B_DEBUG_STEPS: waves by last checkpoint of this launch (0 = none): "); for (int i = 0; i < 8; ++i) fprintf(stderr, "%d:%d ", i, hist[i]); fprintf(stderr, "\n");
+              int shown = 0; for (int b = 0; b < a_.gridF && shown < 12; ++b) for (int w = 0; w < 8 && shown < 12; ++w) { const int v = pg[(size_t)b * 8 + w]; if ((v >> 8) != t || (v & 15) < 4) { fprintf(stderr, "  block %d wave %d: launch %d checkpoint %d\n", b, w, v >> 8, v & 15); ++shown; } } }
+            fprintf(stderr, "S4B_DEBUG_STEPS: launch t = %d of sweep %lld did not finish within 3 s; error / marker word 0x%x\n", t, (long long)dbgSweepNo_, hw); fflush(stderr); std::quick_exit(3); }
+      }
+#endif
+    }
+#ifdef S4B_TUNING
+    ++dbgSweepNo_;
+#endif
     // the generator alternates between two slots by launch parity; between sweeps it lives in slot 0 (a_.rng)
     if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_));
   }
@@ -2828,7 +2866,7 @@ class DevHip {
   enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_SWEEP = 4 };
   bool sweepOk_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
   int64_t sweepCount_ = 0, sweepHandOvers_ = 0;
-  int xbufParity_ = 0;
+  int xbufParity_ = 0; long long dbgSweepNo_ = 0;
   OffsetArgs pend_; bool pendOffset_ = false, pendSigma_ = false;   // Stan -> BART hand-off calls held for the one-launch form (offset_from_params)
   int pathReq_ = 0, path_ = 0, sharing_ = 1;
   double dbgSweepMs_ = 0; int dbgSweeps_ = 0;

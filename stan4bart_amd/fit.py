@@ -147,8 +147,12 @@ def init_fit(y, Xc, groups, n, is_binary):
     for _ in range(25):
         dmu = np.exp(-0.5 * eta * eta) / np.sqrt(2.0 * np.pi)
         var = mu * (1.0 - mu)
-        wt = dmu * dmu / var
-        z = eta + (y - mu) / dmu
+        # glm.fit: `good <- weights > 0 & mu.eta.val != 0` — observations whose fitted probability has run to 0 or 1 (separation)
+        # carry no weight in this step instead of dividing by zero
+        good = (dmu > 0.0) & (var > 0.0)
+        safe = np.where(good, dmu, 1.0)
+        wt = np.where(good, safe * safe / np.where(good, var, 1.0), 0.0)
+        z = np.where(good, eta + (y - mu) / safe, eta)
         coef, _ = wls(wt, z)
         eta = A @ coef
         mu = np.clip(ndtr(eta), 1e-15, 1.0 - 1e-15)

@@ -60,6 +60,9 @@ def random_case(seed):
         bart_args["split.probs"] = np.exp(g2.normal(size=p) * g2.choice([0.3, 2.0]))
     if g2.random() < 0.2:
         bart_args["useQuantiles"] = True
+    big_trees = bool(g2.random() < 0.25) and 400 <= n <= 4000      # trees drawn from a very deep prior: more than 64 node slots from the first sweep on
+    if big_trees:
+        bart_args.update(base=0.99, power=0.25, k=0.3)
     warmup = int(g.integers(2, 12))
     it = warmup + int(g.integers(4, 40 if deep else 25))
     n_test = int(g.integers(0, 3)) * int(g.integers(1, min(n, 20)))
@@ -75,9 +78,11 @@ def random_case(seed):
     capacity = bool(g.random() < 0.1)
     if capacity:
         args.node_capacity = 3000          # (the control code's global-memory path)
+    elif big_trees:
+        args.node_capacity = 1024          # (persistent sweeps hand over to k_step launches)
     what = {k: v for k, v in bart_args.items() if k != "split.probs"}
     return args, joint, dict(n=n, p=p, binary=binary, ranef=ranef, deep=deep, joint=joint, weights=weights is not None, capacity=capacity,
-                             split_probs="split.probs" in bart_args, **what)
+                             split_probs="split.probs" in bart_args, big_trees=big_trees, **what)
 
 
 @pytest.mark.parametrize("path", PATHS)
