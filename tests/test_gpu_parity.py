@@ -403,3 +403,17 @@ def test_handed_over_sweeps_in_a_joint_chain(oracle_lib, hip_lib, hmc_mode):
     sweeps, handed_over = b["sweep_stats"]
     assert sweeps == 12 and handed_over > 0, b["sweep_stats"]
     assert_chain_parity(a, b)
+
+
+def test_hand_over_with_every_workgroup_resident(oracle_lib, hip_lib):
+    """n = 3e5: all 256 workgroups of k_sweep take part in the hand-over (tickets drawn across the 8 XCDs), trees of 12 ... 54 leaves drawn
+    from a deep prior: every sweep starts persistent and ends as k_step launches"""
+    args, _ = friedman_case(n=300000, T=6, warmup=2, iter=5, ranef=False, bart_args={"base": 0.99, "power": 0.3, "k": 0.3})
+    args.node_capacity = 1024
+    a = run_chain(oracle_lib, "orc_", args, results_type=1)
+    assert a["trace"][:, 4].max() > 32
+    for path in ("persistent", "fused"):
+        b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path=path)
+        assert_chain_parity(a, b, stan=False)
+        if path == "persistent":
+            assert b["tree_path"][1] == "persistent" and b["sweep_stats"] == (6, 6)
