@@ -2524,8 +2524,8 @@ class DevHip {
 #ifdef S4B_SWEEP_TIMING
     { unsigned long long h[96]; sweep_timing_fetch(h);
       const double k = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0;
-      fprintf(stderr, "SWEEP workgroup 100 (avg over %llu steps, %.2f bins, %llu routed after the decision) | pass waves, us after the previous publish: totals gathered (wave 3) %.2f; wave 4: images there %.2f, routed %.2f, tables + proposal there %.2f, arithmetic done %.2f; published (wave 3) = step %.2f | decider, us after its previous step: totals seen %.2f, verdict %.2f, tables out %.2f, step end %.2f | image wave 1, us after its previous image: starts drawing %.2f, drawn %.2f\n",
-              h[0], h[0] ? (double)h[7] / (double)h[0] : 0.0, h[8], h[1] * k, h[2] * k, h[3] * k, h[4] * k, h[5] * k, h[6] * k, h[9] * k, h[10] * k, h[11] * k, h[12] * k, h[13] * k, h[14] * k);
+      fprintf(stderr, "SWEEP workgroup 100 (avg over %llu steps, %.2f bins, %llu routed after the decision) | pass waves, us after the previous publish: totals gathered (wave 3) %.2f; wave 4: images there %.2f, routed %.2f, tables + proposal there %.2f, arithmetic done %.2f; published (wave 3) = step %.2f | decider, us after its previous step: totals seen %.2f, verdict %.2f, tables out %.2f, step end %.2f\n",
+              h[0], h[0] ? (double)h[7] / (double)h[0] : 0.0, h[8], h[1] * k, h[2] * k, h[3] * k, h[4] * k, h[5] * k, h[6] * k, h[9] * k, h[10] * k, h[11] * k, h[12] * k);
       fprintf(stderr, "SWEEP steps whose leaf values went out with the verdict (move not accepted, wave 3's values): %llu of %llu\n", h[35], h[0]);
       { auto A = [&](int i) { return (double)(long long)h[i] * k; };
         fprintf(stderr, "SWEEP timeline of a step, us after this workgroup saw the totals complete: wave 3's leaf values %.2f | decider: sees totals %.2f, verdict + old values out %.2f, new values out %.2f | proposal settled %.2f (x%.2f) | wave 5: (routed %.2f) past foldReady %.2f, old values folded %.2f, tables + proposal seen %.2f, new values folded %.2f, statistics reduced %.2f | wave 4: published %.2f | next totals complete = step %.2f\n",
