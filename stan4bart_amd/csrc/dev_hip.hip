@@ -15,6 +15,7 @@
 // trees is a pure launch sequence with no host round trip.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 #include <chrono>
 
 #include <cstdio>
@@ -2253,7 +2254,15 @@ class DevHip {
   }
   // persistent path: one k_sweep launch per sweep; the status word (host-visible) says how far it got: T + 1 = the whole sweep,
   // t in 1..T = k_step launches t..T finish it (a tree outgrew the wave-register control path), 0 = nothing done (tree 0 did)
+  // A persistent sweep needs every workgroup of its launch resident: two such launches interleaved on one device would wait for each
+  // other's compute units.  Samplers of ONE process (threads: stan4bart(cores > 1) without the sharing hint, a C caller's own threads)
+  // therefore take turns — the lock is held from the launch until the host has seen the launch end.  Other processes cannot be
+  // kept out this way (s4b_set_device_sharing; the bounded waits turn such a collision into an error, not a hang).
+  static std::mutex& sweep_mutex(int device) { static std::mutex m[64]; return m[device & 63]; }
+  std::unique_lock<std::mutex> sweepLock_;
   void sweep_persistent_launch() {
+    if (sweepLock_.owns_lock()) sweepLock_.unlock();      // (a previous launch whose end an exception kept us from seeing)
+    sweepLock_ = std::unique_lock<std::mutex>(sweep_mutex(device_));
     for (int i = 0; i < 16; ++i) sweepStatus_[i] = 0;
     sweepStatus_[0] = -1;
     hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
@@ -2268,6 +2277,7 @@ class DevHip {
   // the launch has ended (the caller waited for it or for something behind it on the stream): true = the sweep is complete, false = the
   // rest of it was handed over and has just been queued as k_step launches
   bool sweep_persistent_finish() {
+    if (sweepLock_.owns_lock()) sweepLock_.unlock();
     const int st = sweepStatus_[0];
     ++sweepCount_;
     if (st == T_ + 1) return true;
@@ -2503,11 +2513,14 @@ class DevHip {
 #endif
     for (int sIdx = 0; sIdx < nSweeps * thin; ++sIdx) {
       const int64_t ho = sweepHandOvers_;
-      HIP_OK(hipEventRecord(evStart_, stream_));
-      sweepStatus_[0] = -1;
-      hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
-      HIP_OK(hipEventRecord(evStop_, stream_));
-      sync();
+      {
+        std::lock_guard<std::mutex> turn(sweep_mutex(device_));
+        HIP_OK(hipEventRecord(evStart_, stream_));
+        sweepStatus_[0] = -1;
+        hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
+        HIP_OK(hipEventRecord(evStop_, stream_));
+        sync();
+      }
       const int st = sweepStatus_[0];
       ++sweepCount_;
       if (st < 0 || st > T_ + 1) throw std::runtime_error("persistent tree sweep: the launch did not complete");

@@ -417,3 +417,29 @@ def test_hand_over_with_every_workgroup_resident(oracle_lib, hip_lib):
         assert_chain_parity(a, b, stan=False)
         if path == "persistent":
             assert b["tree_path"][1] == "persistent" and b["sweep_stats"] == (6, 6)
+
+
+def test_two_samplers_in_two_threads_take_turns_on_the_persistent_path(hip_lib):
+    """Samplers of one process that share a device without saying so (no s4b_set_device_sharing): persistent sweeps need every workgroup
+    resident, so the library serialises them per device.  Two chains driven from two threads finish and draw exactly what each draws alone."""
+    import threading
+    args, _ = friedman_case(n=60000, T=30, warmup=5, iter=12, ranef=True)
+    alone = run_chain(hip_lib, "s4b_", args, seed=777, tree_path="persistent")
+    assert alone["tree_path"][1] == "persistent"
+    results, errors = {}, []
+
+    def work(k):
+        try:
+            results[k] = run_chain(hip_lib, "s4b_", args, seed=777, tree_path="persistent")
+        except Exception as e:          # pragma: no cover
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for k in range(2):
+        assert results[k]["tree_path"][1] == "persistent"
+        assert np.array_equal(results[k]["trace"], alone["trace"]) and np.array_equal(results[k]["rng"], alone["rng"])
+        np.testing.assert_array_equal(results[k]["sample"]["stan"], alone["sample"]["stan"])
