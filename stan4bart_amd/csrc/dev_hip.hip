@@ -2029,6 +2029,8 @@ class DevHip {
         hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, device_));
         sweepOk_ = fusedOk_ && d.weights == nullptr && nQuads <= (int64_t)(a.gridF - 1) * SW_PT * SW_PF && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount &&
                    sweep_lds_bytes() + 40 * 1024 <= 160 * 1024;
+        // at most 4096 observations: ONE workgroup holds them all and does the control duties too (no exchange: dev_sweep.inc "solo")
+        sweepGrid_ = nQuads <= (int64_t)SW_PT * SW_PF ? 1 : a.gridF;
         if (sweepOk_) {
           xbuf_ = zalloc<unsigned long long>((size_t)2 * XC_RING * XC_BUF_WORDS);   // two rings: a launch uses one and clears the other for the next launch
           HIP_OK(hipHostMalloc(&sweepStatus_, 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -2265,7 +2267,7 @@ class DevHip {
     sweepLock_ = std::unique_lock<std::mutex>(sweep_mutex(device_));
     for (int i = 0; i < 16; ++i) sweepStatus_[i] = 0;
     sweepStatus_[0] = -1;
-    hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
+    hipLaunchKernelGGL(k_sweep, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
     HIP_OK(hipGetLastError());
   }
   SweepArgs sweep_args() {     // (the exchange ring of this launch, the one it clears for the next launch)
@@ -2517,7 +2519,7 @@ class DevHip {
         std::lock_guard<std::mutex> turn(sweep_mutex(device_));
         HIP_OK(hipEventRecord(evStart_, stream_));
         sweepStatus_[0] = -1;
-        hipLaunchKernelGGL(k_sweep, dim3(a_.gridF), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
+        hipLaunchKernelGGL(k_sweep, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
         HIP_OK(hipEventRecord(evStop_, stream_));
         sync();
       }
@@ -2879,7 +2881,7 @@ class DevHip {
   enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_SWEEP = 4 };
   bool sweepOk_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
   int64_t sweepCount_ = 0, sweepHandOvers_ = 0;
-  int xbufParity_ = 0; long long dbgSweepNo_ = 0;
+  int xbufParity_ = 0; long long dbgSweepNo_ = 0; int sweepGrid_ = 0;
   OffsetArgs pend_; bool pendOffset_ = false, pendSigma_ = false;   // Stan -> BART hand-off calls held for the one-launch form (offset_from_params)
   int pathReq_ = 0, path_ = 0, sharing_ = 1;
   double dbgSweepMs_ = 0; int dbgSweeps_ = 0;
