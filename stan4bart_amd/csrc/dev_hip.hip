@@ -2031,6 +2031,9 @@ class DevHip {
                    sweep_lds_bytes() + 40 * 1024 <= 160 * 1024;
         // at most 4096 observations: ONE workgroup holds them all and does the control duties too (no exchange: dev_sweep.inc "solo")
         sweepGrid_ = nQuads <= (int64_t)SW_PT * SW_PF ? 1 : a.gridF;
+#ifdef S4B_TUNING
+        if (getenv("S4B_NOSOLO")) sweepGrid_ = a.gridF;
+#endif
         if (sweepOk_) {
           xbuf_ = zalloc<unsigned long long>((size_t)2 * XC_RING * XC_BUF_WORDS);   // two rings: a launch uses one and clears the other for the next launch
           HIP_OK(hipHostMalloc(&sweepStatus_, 64, hipHostMallocCoherent | hipHostMallocMapped));

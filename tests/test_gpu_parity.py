@@ -443,3 +443,22 @@ def test_two_samplers_in_two_threads_take_turns_on_the_persistent_path(hip_lib):
         assert results[k]["tree_path"][1] == "persistent"
         assert np.array_equal(results[k]["trace"], alone["trace"]) and np.array_equal(results[k]["rng"], alone["rng"])
         np.testing.assert_array_equal(results[k]["sample"]["stan"], alone["sample"]["stan"])
+
+
+def test_hand_over_from_the_one_workgroup_sweep(oracle_lib, hip_lib):
+    """At most 4096 observations: k_sweep runs as ONE workgroup (no exchange), while the k_step launches that finish a handed-over sweep use
+    their own geometry (here two pass workgroups).  Regression (fuzz seed 3738): the hand-over summed the per-workgroup partial slots of
+    k_step's geometry — the second one stale from an earlier sweep — instead of the one slot the single workgroup had written."""
+    from stan4bart_amd import make_sampler_args
+    g = np.random.default_rng(3738)
+    n = 2317
+    xb = np.column_stack([g.normal(size=n), g.random(n), (g.random(n) < 0.3).astype(np.float64)])
+    x4 = g.random(n)
+    y = 3.0 * np.sin(2.0 * xb[:, 0]) + 2.0 * (xb[:, 2] > 0.5) + 1.5 * x4 + g.normal(size=n)
+    args = make_sampler_args(y, xb, X=x4[:, None], groups=[], iter=14, warmup=6, bart_args={"n.trees": 8, "n.cuts": 5, "k": 0.3, "base": 0.99, "power": 0.25})
+    args.node_capacity = 1024
+    a = run_chain(oracle_lib, "orc_", args, results_type=1)
+    assert a["trace"][:, 4].max() > 32
+    b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path="persistent")
+    assert b["tree_path"][1] == "persistent" and b["sweep_stats"][1] >= 10
+    assert_chain_parity(a, b, stan=False)
