@@ -3,10 +3,10 @@
 import pytest
 
 from conftest import assert_chain_parity, run_chain
-from test_gpu_fuzz import random_case
+from test_gpu_fuzz import REGRESSION_SEEDS, random_case
 
 
-@pytest.mark.parametrize("seed", range(160))
+@pytest.mark.parametrize("seed", list(range(160)) + REGRESSION_SEEDS)
 def test_random_configuration_host_logic(oracle_lib, emul_lib, seed):
     args, joint, what = random_case(seed)
     rt = 0 if joint else 1

@@ -101,3 +101,22 @@ def test_random_configuration(oracle_lib, hip_lib, seed, path):
         assert_chain_parity(a, b, stan=joint)
     except AssertionError as e:
         raise AssertionError(f"seed {seed} on the {path} path, case {what}: {e}") from e
+
+
+# seeds outside 0 .. 159 that once failed (tools/fuzz_range.py campaigns): 280 — k_step proposed for a tree beyond the wave path
+# (a launch that never returned); 2576 — ticket word of k_sweep's hand-over reset with a plain store; 3738, 8116, 10079 — stale partial
+# slots in the hand-over of the one-workgroup sweep
+REGRESSION_SEEDS = [280, 2576, 3738, 8116, 10079]
+
+
+@pytest.mark.parametrize("path", PATHS)
+@pytest.mark.parametrize("seed", REGRESSION_SEEDS)
+def test_seeds_that_once_failed(oracle_lib, hip_lib, seed, path):
+    args, joint, what = random_case(seed)
+    rt = 0 if joint else 1
+    a = run_chain(oracle_lib, "orc_", args, results_type=rt)
+    b = run_chain(hip_lib, "s4b_", args, results_type=rt, tree_path=path)
+    try:
+        assert_chain_parity(a, b, stan=joint)
+    except AssertionError as e:
+        raise AssertionError(f"seed {seed} on the {path} path, case {what}: {e}") from e
