@@ -2303,7 +2303,9 @@ class DevHip {
   }
   void sweep_persistent_one() {
     sweep_persistent_launch();
-    HIP_OK(hipStreamSynchronize(stream_));
+    const hipError_t e = hipStreamSynchronize(stream_);
+    if (e != hipSuccess && sweepLock_.owns_lock()) sweepLock_.unlock();
+    HIP_OK(e);
     sweep_persistent_finish();
   }
   // The Gibbs iteration's sweep followed by the Stan block's inputs (sampler_core.hpp run()).  On the persistent path the host does not
@@ -2314,7 +2316,8 @@ class DevHip {
     if (path_ != PATH_SWEEP || binary_ || thin < 1) { sweep(thin); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); return; }
     for (int k = 0; k + 1 < thin; ++k) sweep_persistent_one();
     sweep_persistent_launch();
-    stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut);
+    try { stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); }
+    catch (...) { if (sweepLock_.owns_lock()) sweepLock_.unlock(); throw; }      // (never keep the device's turn across an error)
     if (!sweep_persistent_finish()) stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut);
   }
   void sweep_impl(int thin) {
