@@ -345,7 +345,7 @@ def main():
     # ---- phase 2: sampling.  W untimed, then exactly K timed Gibbs iterations
     if a.warmup > 0:
         sampler.run(a.warmup, False, 0)
-    state_after_burn_in = sampler.get_state() if (rank == 0 and world == 1 and not a.no_cpu_baseline and not a.emul) else None
+    state_after_burn_in = sampler.get_state() if (rank == 0 and world == 1 and not a.emul and not (a.no_cpu_baseline and a.no_hmc_mode1)) else None
     barrier()
     c0, s0 = sampler.get_counters(), sampler.get_nuts_stats()
     t0 = time.perf_counter()
@@ -363,6 +363,21 @@ def main():
     # start from the same state and generator positions, so they do the same leapfrogs up to rounding.
     dt1 = None
     modes = None
+    # ---- the headline's own K iterations once more with one O(N) device evaluation per leapfrog (hmc_mode 1): the chain goes back to the
+    # state it had when the timed region began (same trees, same generator positions: the same leapfrogs up to rounding)
+    window1 = None
+    if state_after_burn_in is not None and not a.no_hmc_mode1:
+        sampler.set_state(state_after_burn_in)
+        sampler.set_hmc_mode(1)
+        m0 = sampler.get_nuts_stats()
+        t0w = time.perf_counter()
+        sampler.run(a.steps, False, 0)
+        torch.cuda.synchronize()
+        dtw = time.perf_counter() - t0w
+        window1 = {"value": a.steps / dtw, "unit": "Gibbs iterations/s/chain", "ms_per_step": 1e3 * dtw / a.steps,
+                   "n_leapfrog_per_step": (sampler.get_nuts_stats()["sum_n_leapfrog"] - m0["sum_n_leapfrog"]) / a.steps,
+                   "note": "hmc_mode 1 over the SAME iterations as the headline (chain put back to the state at the start of the timed region)"}
+        sampler.set_hmc_mode(hmc_mode)
     if not a.no_hmc_mode1 and not a.emul:
         state0 = sampler.get_state()
         legs = {}
@@ -451,6 +466,8 @@ def main():
             rec["per_chain_hmc_mode1"] = {"value": a.mode_iters / dt1_max, "unit": "Gibbs iterations/s/chain", "ms_per_step": 1e3 * dt1_max / a.mode_iters,
                                           "n_leapfrog_per_step": modes[1][1],
                                           "note": "hmc_mode 1 (every leapfrog launches k_stan_fused over all N observations) over the iterations of gradient_modes_same_iterations"}
+        if window1 is not None:
+            rec["per_chain_hmc_mode1_headline_window"] = window1
         if prof is not None:
             # HBM traffic of the tree kernel: REPLAYED from the PMC passes committed under profiles/ (rocprofv3 cannot wrap this
             # process from inside; collected on this command line by tools/profile_round.sh, see profiles/pmc_traffic.json)
