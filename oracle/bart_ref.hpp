@@ -273,7 +273,8 @@ class BartFit {
         std::vector<double> sorted(uniq.begin(), uniq.end());
         const size_t nu = sorted.size(), maxCuts = (size_t)nCuts[j];
         size_t nc, step, offset;
-        if (nu <= maxCuts + 1) { nc = nu - 1; step = 1; offset = 0; } else { nc = maxCuts; step = nu / nc; offset = step / 2; }
+        if (maxCuts == 0) { nc = 0; step = 1; offset = 0; }   // (no cut requested: the column takes no rule)
+        else if (nu <= maxCuts + 1) { nc = nu - 1; step = 1; offset = 0; } else { nc = maxCuts; step = nu / nc; offset = step / 2; }
         numCuts[j] = (int)nc; cuts[j].resize(nc);
         for (size_t k = 0; k < nc; ++k) { const size_t idx = std::min(k * step + offset, nu - 2); cuts[j][k] = 0.5 * (sorted[idx] + sorted[idx + 1]); }
         continue;

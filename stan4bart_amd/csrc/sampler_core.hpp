@@ -166,6 +166,8 @@ class SamplerCore {
       for (int64_t e = 0; e < sd->num_non_zero; ++e) if (sd->v[e] < 0 || sd->v[e] >= sd->q) throw std::invalid_argument("CSR column index out of range");
     }
     model_.reset(new HostModel(sp));
+    // test hook (tests/test_priors.py): 1 = reverse-mode tape for every gradient, 2 = closed form AND tape, compared on every evaluation
+    if (const char* e = std::getenv("S4B_GRADIENT_CHECK")) model_->gradientCheck = std::atoi(e);
     K_ = sd->K; q_ = sd->q; hmcMode_ = sc->hmc_mode;
     cX_.assign((size_t)K_, 0.0); cZ_.assign((size_t)q_, 0.0);
 
@@ -696,7 +698,8 @@ class SamplerCore {
         u.erase(std::unique(u.begin(), u.end()), u.end());
         const size_t nu = u.size();
         size_t numCuts, step, offset;
-        if (nu <= (size_t)m + 1) { numCuts = nu - 1; step = 1; offset = 0; }
+        if (m == 0) { numCuts = 0; step = 1; offset = 0; }      // n_cuts = 0 is a legal request: no rule can use the column (nu / numCuts below would divide by zero)
+        else if (nu <= (size_t)m + 1) { numCuts = nu - 1; step = 1; offset = 0; }
         else { numCuts = (size_t)m; step = nu / numCuts; offset = step / 2; }
         cuts_[(size_t)j].resize(numCuts);
         for (size_t k = 0; k < numCuts; ++k) {
@@ -790,6 +793,14 @@ class SamplerCore {
         for (int b = 0; b < M; ++b) if (dense[(size_t)a * M + b] != 0.0) { gramCol_.push_back(b); gram_.push_back(dense[(size_t)a * M + b]); }
         gramPtr_[(size_t)a + 1] = (int)gramCol_.size();
       }
+      // a few dozen coefficients whose Gram matrix is mostly filled (crossed grouping factors): rows padded to a multiple of four, so that
+      // the matrix-vector product of a leapfrog is straight vector code instead of indexed loads
+      gramDense_.clear(); gramLd_ = 0;
+      if (M <= 64 && gramCol_.size() * 3 >= (size_t)M * M) {
+        gramLd_ = (M + 3) & ~3;
+        gramDense_.assign((size_t)M * gramLd_, 0.0);
+        for (int a = 0; a < M; ++a) for (int b = 0; b < M; ++b) gramDense_[(size_t)a * gramLd_ + b] = dense[(size_t)a * M + b];
+      }
       return;
     }
     // many groups (e.g. a grouping factor with 1e5 levels): G is never formed densely.  Entries are accumulated per (row, column)
@@ -816,10 +827,24 @@ class SamplerCore {
     // (hundreds of calls per Gibbs iteration once the chain runs deep NUTS trees: theta = [beta; b] contiguous, no branch per entry;
     // same products in the same order as the two-array form)
     const int M = K_ + q_;
-    if (thetaBuf_.size() < (size_t)M) thetaBuf_.resize((size_t)M);
+    if (thetaBuf_.size() < (size_t)M + 4) thetaBuf_.assign((size_t)M + 4, 0.0);
     double* const th = thetaBuf_.data();
     for (int k = 0; k < K_; ++k) th[k] = beta[k];
     for (int j = 0; j < q_; ++j) th[K_ + j] = b[j];
+    if (gramLd_) {
+      const double* const G = gramDense_.data(); const int ld = gramLd_;
+      double ss = s0_;
+      for (int a = 0; a < M; ++a) {
+        const double* const r = G + (size_t)a * ld;
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        for (int c = 0; c < ld; c += 4) { p0 += r[c] * th[c]; p1 += r[c + 1] * th[c + 1]; p2 += r[c + 2] * th[c + 2]; p3 += r[c + 3] * th[c + 3]; }
+        const double ga = (p0 + p2) + (p1 + p3);
+        const double ca = a < K_ ? cX_[(size_t)a] : cZ_[(size_t)(a - K_)];
+        ss += th[a] * (ga - 2.0 * ca);
+        if (a < K_) gX[a] = ca - ga; else gZ[a - K_] = ca - ga;
+      }
+      return ss;
+    }
     const int* const ptr = gramPtr_.data(); const int* const col = gramCol_.data(); const double* const g = gram_.data();
     double ss = s0_;
     for (int a = 0; a < M; ++a) {
@@ -851,7 +876,7 @@ class SamplerCore {
   std::unique_ptr<HostModel> model_; std::unique_ptr<Nuts> nuts_;
   bool keepTrees_ = false;
   std::vector<PackedNode> keptNodes_; std::vector<int64_t> keptTreeStart_; std::vector<double> keptScale_;
-  std::vector<double> row_, cX_, cZ_, gram_; std::vector<int> gramPtr_, gramCol_; double s0_ = 0, sigma_ = 1;
+  std::vector<double> row_, cX_, cZ_, gram_, gramDense_; int gramLd_ = 0; std::vector<int> gramPtr_, gramCol_; double s0_ = 0, sigma_ = 1;
   long treeUpdates_ = 0;
 };
 

@@ -13,6 +13,7 @@
 #ifndef S4B_STAN_HOST_HPP
 #define S4B_STAN_HOST_HPP
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <functional>
@@ -167,7 +168,9 @@ class HostModel {
   StanSpec sp;
   Likelihood lik;
   long gradEvals = 0;
-  explicit HostModel(const StanSpec& s) : sp(s) { sp.finish(); }
+  explicit HostModel(const StanSpec& s) : sp(s) { sp.finish(); plan_closed_form(); }
+  // (test hook) 0: the closed-form gradient where it applies (default); 1: the tape everywhere; 2: both, compared (throws on a difference)
+  int gradientCheck = 0;
 
   struct Fwd { TV sigma; std::vector<TV> beta, b, theta_L, constrained; TV lp; bool wantConstrained = true; };
 
@@ -312,6 +315,30 @@ class HostModel {
   }
 
   double log_prob_grad(const std::vector<double>& qv, std::vector<double>& grad) {
+    if (closedForm_ && gradientCheck != 1) {
+      ++gradEvals;
+      grad.resize((size_t)sp.D);
+      const double lp = closed_form_grad(qv.data(), grad.data());
+      if (gradientCheck == 2) {
+        std::vector<double> g2; const double lp2 = tape_grad(qv, g2); --gradEvals;
+        // (far outside the typical set — a diverging trajectory — components of 1e9 are differences of terms of 1e17: the two
+        // evaluation orders then agree to the conditioning of the sum, not to 1e-9 of the component)
+        double gmax = 0.0; for (double x : g2) if (std::isfinite(x)) gmax = std::max(gmax, std::fabs(x));
+        auto off = [gmax](double a, double b) { return std::fabs(a - b) > 1e-9 * (std::fabs(a) + std::fabs(b)) + 1e-11 * gmax + 1e-300 && !(std::isnan(a) && std::isnan(b)) && !(std::isinf(a) && a == b); };
+        bool bad = off(lp, lp2);
+        for (int i = 0; i < sp.D; ++i) bad = bad || off(grad[(size_t)i], g2[(size_t)i]);
+        if (bad) {
+          std::string m = "closed-form gradient differs from the tape: lp " + std::to_string(lp) + " vs " + std::to_string(lp2);
+          char buf[96];
+          for (int i = 0; i < sp.D; ++i) if (off(grad[(size_t)i], g2[(size_t)i])) { std::snprintf(buf, sizeof buf, "; g[%d] %.17g vs %.17g (q %.6g)", i, grad[(size_t)i], g2[(size_t)i], qv[(size_t)i]); m += buf; }
+          throw std::logic_error(m);
+        }
+      }
+      return lp;
+    }
+    return tape_grad(qv, grad);
+  }
+  double tape_grad(const std::vector<double>& qv, std::vector<double>& grad) {
     ++gradEvals;
     Fwd& F = fwd_; std::vector<int>& qidx = qidx_;
     F.wantConstrained = false;
@@ -366,7 +393,160 @@ class HostModel {
     for (auto& x : F.theta_L) out[o++] = x.v();
   }
 
+  bool has_closed_form() const { return closedForm_; }
+
  private:
+  // ---- closed-form gradient of the default model family -----------------------------------------------------------------------------
+  // Once the chain runs deep NUTS trees (~1000 leapfrogs per Gibbs iteration at n = 1e6) the O(D) part of a gradient IS the Stan block's
+  // cost in hmc_mode 0.  For the configuration the reference fits by default — normal (or flat) coefficient prior, decov with at most
+  // two coefficients per grouping term (random intercepts, one random slope), any aux prior — log pi and its gradient are written out
+  // below: the same quantities as forward() (reference continuous.stan:261-429, make_theta_L :2-59, make_b :61-94, decov_lp :96-122)
+  // without tape nodes.  Everything else (hs / laplace / lasso / product_normal / student_t coefficients, p_i > 2) stays on the tape;
+  // tests/test_priors.py and gradientCheck = 2 compare the two.
+  struct CfTerm { int p, l, zb0, rho, zeta, tau; double scale, betaA, lbeta, delta0, delta1, lgDelta0, lgDelta1, shape, lgShape; };
+  struct CfWork { double tau, A, rho, e, z0, z1, S, pi0, pi1, trace, sd1, T21, sq; };   // forward values of one term, kept for the backward pass
+  std::vector<CfWork> cfWork_;
+  bool closedForm_ = false;
+  std::vector<CfTerm> cfTerms_;
+  int cfRho0_ = 0, cfZeta0_ = 0, cfTau0_ = 0, cfAux_ = 0;
+  double cfAuxConst_ = 0;
+  std::vector<double> cfBeta_, cfB_, cfGX_, cfGZ_, cfTh_;
+  void plan_closed_form() {
+    closedForm_ = false;
+    if (sp.prior_dist > 1 || sp.hs || sp.n_mix || sp.n_lambda || sp.len_z_T) return;
+    for (int i = 0; i < sp.t; ++i) if (sp.p[(size_t)i] > 2 || sp.p[(size_t)i] < 1) return;
+    cfRho0_ = sp.K + sp.q; cfZeta0_ = cfRho0_ + sp.len_rho; cfTau0_ = cfZeta0_ + sp.len_conc; cfAux_ = cfTau0_ + sp.t;
+    cfTerms_.clear();
+    int zb = sp.K, rho = cfRho0_, zeta = cfZeta0_, reg = 0, dl = 0;
+    for (int i = 0; i < sp.t; ++i) {
+      CfTerm c{}; c.p = sp.p[(size_t)i]; c.l = sp.l[(size_t)i]; c.zb0 = zb; c.tau = cfTau0_ + i; c.scale = sp.scale[(size_t)i];
+      c.shape = sp.shape[(size_t)i]; c.lgShape = lg(c.shape);
+      c.rho = -1; c.zeta = -1;
+      if (c.p == 2) {
+        c.rho = rho++; c.zeta = zeta; zeta += 2;
+        const double nu = sp.regularization[(size_t)reg++];          // (p = 2: one Beta(nu, nu) on rho)
+        c.betaA = nu; c.lbeta = lg(nu) + lg(nu) - lg(nu + nu);
+        c.delta0 = sp.delta[(size_t)dl]; c.delta1 = sp.delta[(size_t)dl + 1]; dl += 2;
+        c.lgDelta0 = lg(c.delta0); c.lgDelta1 = lg(c.delta1);
+      }
+      zb += c.p * c.l;
+      cfTerms_.push_back(c);
+    }
+    if (!sp.is_binary && sp.prior_dist_for_aux == 2) {
+      const double nu = sp.prior_df_for_aux;
+      cfAuxConst_ = lg((nu + 1.0) / 2.0) - lg(nu / 2.0) - 0.5 * std::log(nu * M_PI);
+    }
+    cfBeta_.assign((size_t)sp.K + 1, 0.0); cfB_.assign((size_t)sp.q + 1, 0.0); cfGX_.assign((size_t)sp.K + 1, 0.0); cfGZ_.assign((size_t)sp.q + 1, 0.0);
+    cfTh_.assign((size_t)(3 * sp.t + 1), 0.0); cfWork_.assign((size_t)sp.t + 1, CfWork{});
+    closedForm_ = true;
+  }
+  double closed_form_grad(const double* q, double* g) {
+    const double HALF_LOG_2PI = 0.91893853320467274178, LOG_HALF = -0.693147180559945286;
+    const int K = sp.K, nq = sp.q, t = sp.t;
+    double lp = 0.0;
+    // ---- aux (sigma)
+    double u = 1.0, aux = 1.0, dAuxDu = 0.0;
+    if (!sp.is_binary) {
+      u = std::exp(q[cfAux_]); lp += q[cfAux_];
+      if (sp.prior_dist_for_aux == 0) { aux = u; dAuxDu = 1.0; }
+      else { aux = u * sp.prior_scale_for_aux; dAuxDu = sp.prior_scale_for_aux; if (sp.prior_dist_for_aux <= 2) aux += sp.prior_mean_for_aux; }
+    }
+    // ---- coefficients
+    double* const beta = cfBeta_.data(); double* const b = cfB_.data();
+    if (sp.prior_dist == 0) for (int k = 0; k < K; ++k) beta[k] = q[k];
+    else for (int k = 0; k < K; ++k) { beta[k] = q[k] * sp.prior_scale[(size_t)k] + sp.prior_mean[(size_t)k]; lp += -0.5 * q[k] * q[k] - HALF_LOG_2PI; }
+    // ---- theta_L, b (T = [[T00, 0], [T10, T11]] per term with two coefficients)
+    double* const th = cfTh_.data();     // per term: T00 (or theta), T10, T11
+    for (int i = 0; i < t; ++i) {
+      const CfTerm& c = cfTerms_[(size_t)i];
+      CfWork& w = cfWork_[(size_t)i];
+      const double tau = std::exp(q[c.tau]); lp += q[c.tau];
+      const double A = tau * c.scale * aux;
+      w.tau = tau; w.A = A;
+      const double* zb = q + c.zb0;
+      double* bo = b + (c.zb0 - K);
+      if (c.p == 1) {
+        th[3 * i] = A;
+        for (int s = 0; s < c.l; ++s) { bo[s] = A * zb[s]; lp += -0.5 * zb[s] * zb[s] - HALF_LOG_2PI; }
+      } else {
+        const double x = q[c.rho], ax = std::fabs(x), e = std::exp(-ax);
+        const double rho = x >= 0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+        lp += -ax - 2.0 * std::log1p(e);
+        const double z0 = std::exp(q[c.zeta]), z1 = std::exp(q[c.zeta + 1]); lp += q[c.zeta] + q[c.zeta + 1];
+        const double trace = A * A * 2.0, S = z0 + z1, pi0 = z0 / S, pi1 = z1 / S;
+        const double sd0 = std::sqrt(pi0 * trace), sd1 = std::sqrt(pi1 * trace), T21 = rho * 2.0 - 1.0, sq = std::sqrt(1.0 - T21 * T21);
+        const double T00 = sd0, T10 = sd1 * T21, T11 = sd1 * sq;
+        th[3 * i] = T00; th[3 * i + 1] = T10; th[3 * i + 2] = T11;
+        w.rho = rho; w.e = e; w.z0 = z0; w.z1 = z1; w.S = S; w.pi0 = pi0; w.pi1 = pi1; w.trace = trace; w.sd1 = sd1; w.T21 = T21; w.sq = sq;
+        for (int j = 0; j < c.l; ++j) {
+          const double a0 = zb[2 * j], a1 = zb[2 * j + 1];
+          bo[2 * j] = T00 * a0; bo[2 * j + 1] = T10 * a0 + T11 * a1;
+          lp += (-0.5 * a0 * a0 - HALF_LOG_2PI) + (-0.5 * a1 * a1 - HALF_LOG_2PI);
+        }
+        lp += std::log(rho) * (c.betaA - 1.0) + std::log1p(-rho) * (c.betaA - 1.0) - c.lbeta;
+        lp += (q[c.zeta] * (c.delta0 - 1.0) - z0 - c.lgDelta0) + (q[c.zeta + 1] * (c.delta1 - 1.0) - z1 - c.lgDelta1);
+      }
+      lp += q[c.tau] * (c.shape - 1.0) - tau - c.lgShape;
+    }
+    // ---- aux prior
+    double dLpDu = 0.0;
+    if (!sp.is_binary && sp.prior_dist_for_aux > 0 && sp.prior_scale_for_aux > 0) {
+      if (sp.prior_dist_for_aux == 1) { lp += (-0.5 * u * u - HALF_LOG_2PI) - LOG_HALF; dLpDu = -u; }
+      else if (sp.prior_dist_for_aux == 2) {
+        const double nu = sp.prior_df_for_aux;
+        lp += std::log(u * u / nu + 1.0) * (-(nu + 1.0) / 2.0) + cfAuxConst_ - LOG_HALF; dLpDu = -(nu + 1.0) * u / (nu + u * u);
+      } else { lp -= u; dLpDu = -1.0; }
+    }
+    // ---- the O(N) part (device kernels or the Gram form)
+    double* const gX = cfGX_.data(); double* const gZ = cfGZ_.data();
+    for (int k = 0; k < K; ++k) gX[k] = 0.0;
+    for (int j = 0; j < nq; ++j) gZ[j] = 0.0;
+    const double ss = lik(beta, b, gX, gZ);
+    const double s2 = aux * aux, N = (double)sp.N, is2 = 1.0 / s2;
+    const double ll = -0.5 * ss / s2 - N * std::log(aux) - N * HALF_LOG_2PI;
+    double dAux = ss / (s2 * aux) - N / aux;
+    // ---- backward
+    if (sp.prior_dist == 0) for (int k = 0; k < K; ++k) g[k] = gX[k] * is2;
+    else for (int k = 0; k < K; ++k) g[k] = gX[k] * is2 * sp.prior_scale[(size_t)k] - q[k];
+    for (int i = 0; i < t; ++i) {
+      const CfTerm& c = cfTerms_[(size_t)i];
+      const double* zb = q + c.zb0; const double* gb = gZ + (c.zb0 - K); double* gz = g + c.zb0;
+      const CfWork& w = cfWork_[(size_t)i];
+      const double tau = w.tau, A = w.A;
+      double dA = 0.0;
+      if (c.p == 1) {
+        double dTh = 0.0;
+        for (int s = 0; s < c.l; ++s) { const double db = gb[s] * is2; dTh += db * zb[s]; gz[s] = db * A - zb[s]; }
+        dA = dTh;
+      } else {
+        const double T00 = th[3 * i], T10 = th[3 * i + 1], T11 = th[3 * i + 2];
+        double d00 = 0.0, d10 = 0.0, d11 = 0.0;
+        for (int j = 0; j < c.l; ++j) {
+          const double a0 = zb[2 * j], a1 = zb[2 * j + 1], db0 = gb[2 * j] * is2, db1 = gb[2 * j + 1] * is2;
+          d00 += db0 * a0; d10 += db1 * a0; d11 += db1 * a1;
+          gz[2 * j] = db0 * T00 + db1 * T10 - a0; gz[2 * j + 1] = db1 * T11 - a1;
+        }
+        const double sg = q[c.rho] >= 0 ? 1.0 : -1.0, e = w.e, rho = w.rho, z0 = w.z0, z1 = w.z1;
+        const double trace = w.trace, S = w.S, pi0 = w.pi0, pi1 = w.pi1, sd0 = T00, sd1 = w.sd1, T21 = w.T21, sq = w.sq;
+        const double dsd0 = d00, dsd1 = d10 * T21 + d11 * sq, dT21 = d10 * sd1 - d11 * sd1 * (T21 / sq);
+        const double dpi0 = dsd0 * trace * (0.5 / sd0), dpi1 = dsd1 * trace * (0.5 / sd1);
+        const double dtrace = dsd0 * pi0 * (0.5 / sd0) + dsd1 * pi1 * (0.5 / sd1);
+        const double dS = -(dpi0 * pi0 + dpi1 * pi1) / S;
+        double dz0 = dpi0 / S + dS, dz1 = dpi1 / S + dS;
+        dA = dtrace * 4.0 * A;
+        double drho = 2.0 * dT21 + (c.betaA - 1.0) / rho - (c.betaA - 1.0) / (1.0 - rho);
+        g[c.rho] = drho * rho * (1.0 - rho) + (-sg + 2.0 * sg * e / (1.0 + e));
+        g[c.zeta] = dz0 * z0 + 1.0 + (c.delta0 - 1.0) - z0;
+        g[c.zeta + 1] = dz1 * z1 + 1.0 + (c.delta1 - 1.0) - z1;
+      }
+      const double dtau = dA * c.scale * aux;
+      dAux += dA * tau * c.scale;
+      g[c.tau] = dtau * tau + 1.0 + (c.shape - 1.0) - tau;
+    }
+    if (!sp.is_binary) g[cfAux_] = (dAux * dAuxDu + dLpDu) * u + 1.0;
+    return lp + ll;
+  }
+
   // the log-gamma constants of the priors depend on the data only: computed once, reused by every gradient
   mutable std::vector<std::pair<double, double>> lgMemo_;
   double lg(double x) const {
@@ -677,58 +857,84 @@ class Nuts {
 
   struct Acc { int n_leapfrog = 0; double sum_metro = 0; };
 
+  // A point a subtree proposes: position, potential and Hamiltonian.  (The reference copies the whole phase-space point,
+  // base_nuts.hpp:283; what is read of a proposal afterwards is its position, its potential (lp__) and H (energy__), and H of a point
+  // is the value the leaf computed from the same p and V.)
+  struct Prop { V q; double Vv = 0, H = 0; };
   // work space of one recursion level of subtree(): allocated once (a level is never active twice at the same time), so that a leapfrog
-  // costs no heap traffic — hundreds of them per Gibbs iteration once the chain runs deep trees
-  struct Level { V p_init_end, sharp_init_end, rho_init, p_final_beg, sharp_final_beg, rho_final, rho_sub, tmp; Pt propose_final; };
+  // costs no heap traffic — about a thousand of them per Gibbs iteration once the chain runs deep trees
+  struct Level { V p_init_end, sharp_init_end, rho_init, p_final_beg, sharp_final_beg, rho_final; Prop propose_final; };
   std::vector<Level> lv_;
   void ensure_levels() {
     if ((int)lv_.size() == max_depth_ + 1) return;
     lv_.resize((size_t)max_depth_ + 1);
-    for (Level& l : lv_) {
-      for (V* v : {&l.p_init_end, &l.sharp_init_end, &l.rho_init, &l.p_final_beg, &l.sharp_final_beg, &l.rho_final, &l.rho_sub, &l.tmp,
-                   &l.propose_final.q, &l.propose_final.p, &l.propose_final.g}) v->assign((size_t)D_, 0.0);
-    }
+    for (Level& l : lv_)
+      for (V* v : {&l.p_init_end, &l.sharp_init_end, &l.rho_init, &l.p_final_beg, &l.sharp_final_beg, &l.rho_final, &l.propose_final.q}) v->assign((size_t)D_, 0.0);
   }
-  static void vadd(const V& a, const V& b, V& r) { for (size_t i = 0; i < a.size(); ++i) r[i] = a[i] + b[i]; }
 
-  bool subtree(int depth, Pt& propose, V& sharp_beg, V& sharp_end, V& rho, V& p_beg, V& p_end, double H0, double sign,
+  // base_nuts::build_tree (base_nuts.hpp:247-352).  Every quantity is computed by the same operations in the same order as the
+  // straightforward transcription (per-element arithmetic; dot products summed from element 0 upwards) — the loops are fused, and the six
+  // dot products of the three U-turn criteria of a merge run side by side (six independent chains of additions instead of six loops that
+  // each wait for their own previous addition): the chains of a sampler are unchanged bit for bit.
+  bool subtree(int depth, Prop& propose, V& sharp_beg, V& sharp_end, V& rho, V& p_beg, V& p_end, double H0, double sign,
                double& lsw, Acc& acc) {
     const double ninf = -std::numeric_limits<double>::infinity();
+    const int D = D_;
     if (depth == 0) {
-      leapfrog(sign * eps_);
+      const double e = sign * eps_, he = 0.5 * e;
+      {
+        double* __restrict__ const p = z_.p.data(); double* __restrict__ const q = z_.q.data();
+        const double* __restrict__ const g = z_.g.data(); const double* __restrict__ const im = inv_metric_.data();
+        for (int i = 0; i < D; ++i) { const double pi = p[i] - he * g[i]; p[i] = pi; q[i] += e * (im[i] * pi); }
+      }
+      grad();
       ++acc.n_leapfrog;
-      double h = finite_or_inf(hamiltonian());
+      double kin = 0.0;
+      {
+        double* __restrict__ const p = z_.p.data(); const double* __restrict__ const g = z_.g.data(); const double* __restrict__ const im = inv_metric_.data();
+        double* __restrict__ const sb = sharp_beg.data(); double* __restrict__ const se = sharp_end.data(); double* __restrict__ const rh = rho.data();
+        double* __restrict__ const pb = p_beg.data(); double* __restrict__ const pe = p_end.data();
+        for (int i = 0; i < D; ++i) {
+          const double pi = p[i] - he * g[i], sh = im[i] * pi;
+          p[i] = pi; kin += pi * sh; sb[i] = sh; se[i] = sh; rh[i] += pi; pb[i] = pi; pe[i] = pi;
+        }
+      }
+      const double hRaw = 0.5 * kin + z_.Vv, h = finite_or_inf(hRaw);
       if (h - H0 > 1000.0) divergent_ = true;
       lsw = lse(lsw, H0 - h);
       acc.sum_metro += (H0 - h > 0) ? 1.0 : std::exp(H0 - h);
-      propose = z_;
-      sharp_beg.resize((size_t)D_);
-      for (int i = 0; i < D_; ++i) sharp_beg[(size_t)i] = inv_metric_[(size_t)i] * z_.p[(size_t)i];
-      sharp_end = sharp_beg;
-      for (int i = 0; i < D_; ++i) rho[(size_t)i] += z_.p[(size_t)i];
-      p_beg = z_.p; p_end = p_beg;
+      std::copy(z_.q.begin(), z_.q.end(), propose.q.begin()); propose.Vv = z_.Vv; propose.H = hRaw;
       return !divergent_;
     }
     Level& L = lv_[(size_t)depth];
     double lsw_init = ninf;
     std::fill(L.rho_init.begin(), L.rho_init.end(), 0.0);
     if (!subtree(depth - 1, propose, sharp_beg, L.sharp_init_end, L.rho_init, p_beg, L.p_init_end, H0, sign, lsw_init, acc)) return false;
-    L.propose_final = z_;
     double lsw_final = ninf;
     std::fill(L.rho_final.begin(), L.rho_final.end(), 0.0);
     if (!subtree(depth - 1, L.propose_final, L.sharp_final_beg, sharp_end, L.rho_final, L.p_final_beg, p_end, H0, sign, lsw_final, acc)) return false;
     double lsw_sub = lse(lsw_init, lsw_final);
     lsw = lse(lsw, lsw_sub);
-    if (lsw_final > lsw_sub) propose = L.propose_final;
-    else if (rng_.u01() < std::exp(lsw_final - lsw_sub)) propose = L.propose_final;
-    vadd(L.rho_init, L.rho_final, L.rho_sub);
-    for (int i = 0; i < D_; ++i) rho[(size_t)i] += L.rho_sub[(size_t)i];
-    bool ok = uturn_ok(sharp_beg, sharp_end, L.rho_sub);
-    vadd(L.rho_init, L.p_final_beg, L.tmp);
-    ok &= uturn_ok(sharp_beg, L.sharp_final_beg, L.tmp);
-    vadd(L.rho_final, L.p_init_end, L.tmp);
-    ok &= uturn_ok(L.sharp_init_end, sharp_end, L.tmp);
-    return ok;
+    if (lsw_final > lsw_sub) std::swap(propose, L.propose_final);      // (the level's slot is overwritten before it is read again)
+    else if (rng_.u01() < std::exp(lsw_final - lsw_sub)) std::swap(propose, L.propose_final);
+    // rho_sub = rho_init + rho_final; rho += rho_sub; the three criteria (base_nuts.hpp:339-351): the whole subtree, its first half
+    // extended by the first momentum of the second, its second half extended by the last momentum of the first
+    double a1 = 0, b1 = 0, a2 = 0, b2 = 0, a3 = 0, b3 = 0;
+    {
+      const double* __restrict__ const ri = L.rho_init.data(); const double* __restrict__ const rf = L.rho_final.data();
+      const double* __restrict__ const pfb = L.p_final_beg.data(); const double* __restrict__ const pie = L.p_init_end.data();
+      const double* __restrict__ const sb = sharp_beg.data(); const double* __restrict__ const se = sharp_end.data();
+      const double* __restrict__ const sfb = L.sharp_final_beg.data(); const double* __restrict__ const sie = L.sharp_init_end.data();
+      double* __restrict__ const rh = rho.data();
+      for (int i = 0; i < D; ++i) {
+        const double rs = ri[i] + rf[i], t2 = ri[i] + pfb[i], t3 = rf[i] + pie[i];
+        rh[i] += rs;
+        a1 += se[i] * rs; b1 += sb[i] * rs;
+        a2 += sfb[i] * t2; b2 += sb[i] * t2;
+        a3 += se[i] * t3; b3 += sie[i] * t3;
+      }
+    }
+    return (a1 > 0 && b1 > 0) & (a2 > 0 && b2 > 0) & (a3 > 0 && b3 > 0);
   }
 
   void nuts_transition() {
@@ -738,14 +944,19 @@ class Nuts {
     ensure_levels();
     z_.q = cont_;
     draw_momentum(); grad();
-    Pt fwd = z_, bck = z_, sample = z_, propose = z_;
-    V p_ff = z_.p, s_ff = sharp(), p_fb = z_.p, s_fb = s_ff, p_bf = z_.p, s_bf = s_ff, p_bb = z_.p, s_bb = s_ff;
-    V rho = z_.p;
-    double lsw = 0, H0 = hamiltonian();
+    const double H0 = hamiltonian();
+    Pt& fwd = tFwd_; Pt& bck = tBck_; fwd = z_; bck = z_;
+    Prop& sample = tSample_; Prop& propose = tPropose_;
+    sample.q = z_.q; sample.Vv = z_.Vv; sample.H = H0; propose = sample;
+    V& p_ff = tV_[0]; V& s_ff = tV_[1]; V& p_fb = tV_[2]; V& s_fb = tV_[3]; V& p_bf = tV_[4]; V& s_bf = tV_[5]; V& p_bb = tV_[6]; V& s_bb = tV_[7];
+    V& rho = tV_[8]; V& rho_f = tV_[9]; V& rho_b = tV_[10];
+    p_ff = z_.p; s_ff = sharp(); p_fb = z_.p; s_fb = s_ff; p_bf = z_.p; s_bf = s_ff; p_bb = z_.p; s_bb = s_ff;
+    rho = z_.p;
+    double lsw = 0;
     Acc acc;
     depth_ = 0; divergent_ = false;
     while (depth_ < max_depth_) {
-      V rho_f((size_t)D_, 0.0), rho_b((size_t)D_, 0.0);
+      rho_f.assign((size_t)D_, 0.0); rho_b.assign((size_t)D_, 0.0);
       bool valid; double lsw_sub = ninf;
       if (rng_.u01() > 0.5) {
         z_ = fwd; rho_b = rho; p_bf = p_ff; s_bf = s_ff;
@@ -770,10 +981,11 @@ class Nuts {
     n_leapfrog_ = acc.n_leapfrog;
     ++nTrans_; sumDepth_ += depth_; sumLeap_ += acc.n_leapfrog; if (divergent_) ++nDiv_;
     accept_ = acc.sum_metro / (double)acc.n_leapfrog;
-    z_ = sample;
-    energy_ = hamiltonian();
+    z_.q = sample.q; z_.Vv = sample.Vv;     // (momentum and gradient are redrawn / recomputed when the next transition starts)
+    energy_ = sample.H;
     cont_ = z_.q; lp_ = -z_.Vv;
   }
+  Pt tFwd_, tBck_; Prop tSample_, tPropose_; V tV_[11];
 
   void transition() {
     nuts_transition();

@@ -293,6 +293,18 @@ def make_sampler_args(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_tes
     )
 
 
+def qr_back_transform(args: SamplerArgs, results: dict) -> None:
+    """QR = TRUE: the ``beta.*`` rows of a chain's draws back to the scale of the design, in place (reference
+    R/stan4bart_fit.R:560-570 does this for every chain).  Every driver of a chain calls it: ``fit_worker`` and ``generics.stan4bart``."""
+    R_inv = (args.extras or {}).get("R_inv")
+    if R_inv is None:
+        return
+    rows = [i for i, nm in enumerate(results["par_names"]) if nm.startswith("beta.")]
+    for ph in ("warmup", "sample"):
+        if ph in results and rows:
+            results[ph]["stan"][rows, :] = R_inv @ results[ph]["stan"][rows, :]
+
+
 def fit_worker(make_sampler: Callable[[SamplerArgs, np.ndarray], Sampler], args: SamplerArgs, rng: RRng) -> dict:
     """reference stan4bart_fit_worker (R/stan4bart_fit.R:33-60): seed Stan from R's stream, create,
     warmup, disengage adaptation, sample.  ``rng`` is advanced in place (PutRNGstate semantics)."""
@@ -307,12 +319,7 @@ def fit_worker(make_sampler: Callable[[SamplerArgs, np.ndarray], Sampler], args:
         sampler.disengage_adaptation()
         results["sample"] = sampler.run(args.iter - args.warmup, False, 0)
         results["par_names"] = sampler.stan_par_names()
-        R_inv = (args.extras or {}).get("R_inv")
-        if R_inv is not None:       # QR = TRUE: coefficient rows back to the scale of the design (reference R/stan4bart_fit.R:560-570)
-            rows = [i for i, nm in enumerate(results["par_names"]) if nm.startswith("beta.")]
-            for ph in ("warmup", "sample"):
-                if ph in results and rows:
-                    results[ph]["stan"][rows, :] = R_inv @ results[ph]["stan"][rows, :]
+        qr_back_transform(args, results)
         results["range.bart"] = sampler.get_bart_data_range()
         if args.keep_trees:
             results["trees"] = sampler.get_trees()

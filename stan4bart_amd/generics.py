@@ -16,7 +16,7 @@ from typing import Callable, Optional, Sequence
 
 import numpy as np
 
-from .fit import GroupTerm, chain_seeds, hip_sampler_factory, make_sampler_args, make_z_csr
+from .fit import GroupTerm, chain_seeds, hip_sampler_factory, make_sampler_args, make_z_csr, qr_back_transform
 from .rcompat import RRng
 
 INT_MAX = 2147483647
@@ -397,6 +397,7 @@ def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=N
             s.disengage_adaptation()
             r["sample"] = s.run(iter - warmup, False, 0)
             r["par_names"] = s.stan_par_names()
+            qr_back_transform(args, r)       # stan_args = {"QR": True}: beta rows back to the design's scale (R/stan4bart_fit.R:560-570)
             r["range.bart"] = s.get_bart_data_range()
             chain_rng.state = s.get_r_rng_state()
         except Exception:

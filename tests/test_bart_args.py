@@ -86,6 +86,25 @@ def test_quantile_cut_points_closed_form(oracle_lib, emul_lib):
             assert 0 <= k < len(expect[int(v)])
 
 
+def test_quantile_cuts_with_a_column_without_cuts(oracle_lib, emul_lib):
+    """n.cuts = 0 for one column is inside the validated range: with useQuantiles = TRUE it used to divide by zero (ADVICE round 4);
+    the column simply takes no rule."""
+    from stan4bart_amd import make_sampler_args
+    g = np.random.default_rng(6)
+    n = 200
+    xb = np.column_stack([g.random(n), np.round(g.normal(size=n), 1), g.random(n)])
+    y = np.sin(3 * xb[:, 0]) + xb[:, 1] + 0.1 * g.normal(size=n)
+    args = make_sampler_args(y, xb, X=g.random(n)[:, None], groups=[], iter=30, warmup=10,
+                             bart_args={"n.trees": 6, "useQuantiles": True, "n.cuts": [12, 0, 7]})
+    outs = [run_chain(oracle_lib, "orc_", args, results_type=1), run_chain(emul_lib, "emu_", args, results_type=1)]
+    assert_chain_parity(outs[0], outs[1], stan=False)
+    for lib, prefix in ((oracle_lib, "orc_"), (emul_lib, "emu_")):
+        cuts = exported_cut_points(lib, prefix, args)
+        assert [len(c) for c in cuts] == [12, 0, 7]
+    for out in outs:
+        assert out["sample"]["bart"]["varcount"][1].sum() == 0 and out["sample"]["bart"]["varcount"].sum() > 0
+
+
 def exported_cut_points(lib, prefix, args):
     """The cut points a sampler holds, read from its exported BART state (stan4bart_exportBARTState; each implementation has its own
     byte layout: oracle/gibbs_ref.cpp orc_export_bart_state, stan4bart_amd/csrc/sampler_core.hpp export_state)."""

@@ -163,3 +163,40 @@ def test_hip_matches_oracle_with_prior_family(oracle_lib, hip_lib, prior):
     a = run_chain(oracle_lib, "orc_", args)
     b = run_chain(hip_lib, "s4b_", args)
     assert_chain_parity(a, b)
+
+
+CLOSED_FORM_CASES = [
+    ("default_intercepts", dict(ranef=True), {}),
+    ("slopes", dict(ranef=True, slopes=True), {}),
+    ("no_ranef", dict(ranef=False), {}),
+    ("flat_coefficients", dict(ranef=True, slopes=True, stan_args={"prior": {"dist": "none"}}), {}),
+    ("aux_flat", dict(ranef=True, slopes=True), dict(prior_dist_for_aux=0)),
+    ("aux_normal", dict(ranef=True, slopes=True), dict(prior_dist_for_aux=1, prior_mean_for_aux=0.3)),
+    ("aux_student_t", dict(ranef=True), dict(prior_dist_for_aux=2, prior_df_for_aux=4.0, prior_mean_for_aux=0.1)),
+    ("decov_shapes", dict(ranef=True, slopes=True, stan_args={"prior_covariance": dict(regularization=2.5, concentration=1.7, shape=1.4, scale=0.8)}), {}),
+]
+
+
+@pytest.mark.parametrize("name,kw,over", CLOSED_FORM_CASES, ids=[c[0] for c in CLOSED_FORM_CASES])
+def test_closed_form_gradient_matches_tape_and_oracle(oracle_lib, emul_lib, monkeypatch, name, kw, over):
+    """The default model family (normal / flat coefficient prior, at most two coefficients per grouping term, any aux prior) has its log
+    density and gradient written out in closed form (stan_host.hpp closed_form_grad) — what a leapfrog costs on the host once the chain runs
+    deep NUTS trees.  With S4B_GRADIENT_CHECK=2 every evaluation of the chain (initialisation, init_stepsize, every leapfrog) is repeated on
+    the reverse-mode tape and compared; the chain itself is compared with the oracle's (reference continuous.stan:261-429)."""
+    from conftest import friedman_case
+    monkeypatch.setenv("S4B_GRADIENT_CHECK", "2")
+    args, _ = friedman_case(n=150, warmup=7, iter=13, T=7, **kw)     # (free-running joint chains: the reference test horizon, DESIGN.md 2)
+    for k, v in over.items():
+        setattr(args, k, v)
+    assert_chain_parity(run_chain(oracle_lib, "orc_", args), run_chain(emul_lib, "emu_", args))
+
+
+def test_closed_form_gradient_binary_and_tape_only_chain(oracle_lib, emul_lib, monkeypatch):
+    from conftest import binary_case, friedman_case
+    monkeypatch.setenv("S4B_GRADIENT_CHECK", "2")
+    args = binary_case(n=160, T=7, warmup=7, iter=13)
+    assert_chain_parity(run_chain(oracle_lib, "orc_", args), run_chain(emul_lib, "emu_", args))
+    # the tape alone (S4B_GRADIENT_CHECK=1) still carries a whole chain of the default family
+    monkeypatch.setenv("S4B_GRADIENT_CHECK", "1")
+    args, _ = friedman_case(n=150, ranef=True, slopes=True, warmup=7, iter=13, T=7)
+    assert_chain_parity(run_chain(oracle_lib, "orc_", args), run_chain(emul_lib, "emu_", args))

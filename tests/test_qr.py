@@ -59,3 +59,56 @@ def test_qr_fit_quality(emul_lib):
     lp_q = (argsp.X @ rq["sample"]["stan"][rows, :]).mean(axis=1)
     lp_p = (argsp.X @ rp["sample"]["stan"][rows, :]).mean(axis=1)
     assert np.corrcoef(lp_q, lp_p)[0, 1] > 0.95
+
+
+def test_stan4bart_qr_back_transforms_every_chain(emul_lib):
+    """generics.stan4bart() runs its chains itself (not through fit_worker) and must map the beta rows back as well
+    (reference R/stan4bart_fit.R:560-570: for every chain).  The same chains without the back-transform give the sampler's own
+    coefficients theta on Q * scale; the fit's `indiv.fixef` must be the linear predictor of those (X_c R_inv theta), for the training and
+    the test sample, and fitted / predict must agree with extract."""
+    from stan4bart_amd import GroupTerm, generate_friedman_data
+    from stan4bart_amd.abi import Sampler
+    from stan4bart_amd.generics import stan4bart
+    import stan4bart_amd.generics as G
+    d = generate_friedman_data(120, ranef=True, causal=True, p=10)
+    x = d["x"]
+    xb = x[:, [j for j in range(10) if j != 3]]
+    X = np.column_stack([x[:, 3], d["z"]])
+    groups = [GroupTerm(d["g1"], None, "g.1"), GroupTerm(d["g2"], None, "g.2")]
+    rows = np.arange(11)
+    gt = [GroupTerm(np.asarray(d["g1"])[rows], None, "g.1"), GroupTerm(np.asarray(d["g2"])[rows], None, "g.2")]
+    kw = dict(X=X, groups=groups, x_bart_test=xb[rows], X_test=X[rows], groups_test=gt, chains=2, seed=5, iter=12, warmup=5,
+              bart_args={"n.trees": 7, "keepTrees": True}, make_sampler=lambda a, st: Sampler(emul_lib, "emu_", a, st))
+    fit = stan4bart(d["y"], xb, stan_args={"QR": True}, **kw)
+    saved = G.qr_back_transform
+    captured = {}
+    try:
+        G.qr_back_transform = lambda args, r: captured.setdefault("R_inv", args.extras["R_inv"])     # the same chains, theta left as sampled
+        raw = stan4bart(d["y"], xb, stan_args={"QR": True}, **kw)
+    finally:
+        G.qr_back_transform = saved
+    R_inv = captured["R_inv"]
+    assert R_inv is not None
+    theta = raw.extract("fixef", combine_chains=False)            # [K, S, chains] in Q space
+    beta = fit.extract("fixef", combine_chains=False)
+    np.testing.assert_allclose(beta, np.einsum("kj,jsc->ksc", R_inv, theta), rtol=1e-12, atol=1e-14)
+    Xc = X - X.mean(axis=0)
+    want = np.einsum("nk,ksc->nsc", Xc @ R_inv, theta)
+    np.testing.assert_allclose(fit.extract("indiv.fixef", combine_chains=False) - fit.extract("indiv.fixef", combine_chains=False).mean(axis=0, keepdims=True),
+                               want - want.mean(axis=0, keepdims=True), rtol=1e-9, atol=1e-9)
+    # the pieces still add up, the test sample equals the duplicated training rows, predict equals extract
+    parts = sum(fit.extract(t, combine_chains=False) for t in ("indiv.bart", "indiv.fixef", "indiv.ranef"))
+    np.testing.assert_allclose(fit.extract("ev", combine_chains=False), parts, rtol=1e-12, atol=1e-12)
+    for t in ("ev", "indiv.fixef"):
+        np.testing.assert_allclose(fit.extract(t, sample="test", combine_chains=False), fit.extract(t, combine_chains=False)[rows], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(fit.predict(x_bart=xb[rows], X=X[rows], groups=gt, type=t, combine_chains=False),
+                                   fit.extract(t, combine_chains=False)[rows], rtol=1e-9, atol=1e-9)
+    for f in (fit, raw):
+        f.close()
+    # and the QR fit tells the same story as the plain one (chains long enough to have found the surface: the generator's
+    # coefficients are 10 for X4 and 5 for z, inst/common/friedmanData.R)
+    kw.update(iter=60, warmup=30, bart_args={"n.trees": 20})
+    fitq, plain = stan4bart(d["y"], xb, stan_args={"QR": True}, **kw), stan4bart(d["y"], xb, **kw)
+    assert np.corrcoef(fitq.fitted("ev"), plain.fitted("ev"))[0, 1] > 0.95
+    assert np.corrcoef(fitq.fitted("indiv.fixef"), plain.fitted("indiv.fixef"))[0, 1] > 0.99
+    np.testing.assert_allclose(fitq.extract("fixef").mean(axis=1), [10.0, 5.0], atol=2.0)
