@@ -10,10 +10,13 @@ A "step" is one Gibbs iteration = one NUTS transition of the Stan block + one BA
 `value` is the whole-job aggregate over all N chains (chains are independent, so scaling is weak);
 `per_chain` is the BASELINE per-chain figure.  Inputs are resident in HBM before the timed region.
 
-What is timed is a RUNNING chain, in the reference's phase order (R/stan4bart_fit.R:49-51: warm-up, disengage adaptation,
-sample): `--burn-in` untimed warm-up iterations with adaptation engaged (step size, metric windows) bring the chain to its
-stationary regime, adaptation is disengaged, then W untimed and exactly K timed iterations of the SAMPLING phase follow.
-Leapfrogs per transition and mean tree depth of the timed iterations are reported in `config`.
+What is timed is a RUNNING chain in its STATIONARY regime, in the reference's phase order (R/stan4bart_fit.R:49-51: warm-up,
+disengage adaptation, sample): `--burn-in` untimed warm-up iterations with adaptation engaged (default 1000 — the reference's default
+fit is 1000 warm-up + 1000 sampling iterations), adaptation is disengaged, then W untimed and exactly K timed iterations of the SAMPLING
+phase follow.  At this size the chain needs several hundred iterations before NUTS reaches the tree depth it then keeps (~1000 leapfrogs
+per transition: DESIGN.md 8); a short burn-in times a transient that is 30 times cheaper in leapfrogs.  `config.stationarity` therefore
+compares the leapfrogs per iteration of the timed window with those of the next `--mode-iters` iterations of the same chain and says
+whether they agree within 20 %; `value` is only a stationary figure when it says so.
 
 Extra objects on the same JSON line:
   roofline            dominant kernel of the sweep, HIP-event timing on the sampler's own stream, against 8 TB/s HBM
@@ -47,6 +50,19 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
 DOMINANT = {"fused": "k_step", "two-kernel": "k_tree", "persistent": "k_sweep"}
+
+
+def source_sha16():
+    """Fingerprint of what produced a line: bench.py + the library's sources.  A committed N = 1 reference line is only compared with a
+    line of the same sources (profiles/bench_n1_reference.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "stan4bart_amd", "csrc")
+    files = [os.path.abspath(__file__)] + sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".inc", ".hpp")) or f == "Makefile")
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def pin_rank_to_cores(local_rank: int, ranks_on_node: int):
@@ -265,11 +281,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--burn-in", type=int, default=150, help="untimed warm-up-phase iterations before the W + K sampling-phase iterations")
+    ap.add_argument("--burn-in", type=int, default=1000, help="untimed warm-up-phase iterations before the W + K sampling-phase iterations (the reference's default warm-up)")
     ap.add_argument("--n", "--num-obs", dest="n", type=int, default=1_000_000)   # (--num-obs: torchrun's own parser trips over a bare --n)
     ap.add_argument("--p", type=int, default=50)
     ap.add_argument("--trees", type=int, default=200)
-    ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--no-hmc-mode1", action="store_true")
@@ -333,6 +349,8 @@ def main():
     rng = RRng(int(chain_seeds(20260101, max(1, world))[rank]))
     args.seed = int(rng.sample_int(2147483647, 1)[0])
     sampler = Sampler(lib, prefix, args, rng.state)     # uploads everything: inputs are HBM-resident from here on
+    if one_device and world > 1 and not a.emul:
+        sampler.set_device_sharing(world)     # rehearsal mode: all ranks share device 0, a persistent launch could not have it to itself
     sampler.set_tree_path(a.tree_path)
     t_created = time.perf_counter()
     # ---- phase 1 (untimed for the metric): warm-up with adaptation engaged, to the stationary regime
@@ -436,7 +454,7 @@ def main():
                                    + (" (BASELINE config 3)" if (n, a.p, a.trees) == (1_000_000, 50, 200) else ""),
                        "chains": world, "hmc_mode": hmc_mode,
                        "hmc_mode_meaning": "0: O(N) sums folded into sufficient statistics once per Gibbs iteration (leapfrogs cost O(nnz Gram) on the host); 1: one O(N) device evaluation per leapfrog",
-                       "tree_path": tree_path, "burn_in": a.burn_in,
+                       "tree_path": tree_path, "burn_in": a.burn_in, "source_sha16": source_sha16(),
                        "n_leapfrog_timed": int(s1["sum_n_leapfrog"] - s0["sum_n_leapfrog"]),
                        "n_leapfrog_per_step": (s1["sum_n_leapfrog"] - s0["sum_n_leapfrog"]) / a.steps,
                        "mean_treedepth_timed": (s1["sum_treedepth"] - s0["sum_treedepth"]) / trans,
@@ -453,12 +471,25 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "bench_n1_reference.json")) as f:
                     ref1 = json.load(f)
-                if ref1.get("config", {}).get("workload") == rec["config"]["workload"]:
+                rc = ref1.get("config", {})
+                same = (rc.get("workload") == rec["config"]["workload"] and rc.get("tree_path") == tree_path and rc.get("burn_in") == a.burn_in
+                        and rc.get("source_sha16") == rec["config"]["source_sha16"])
+                if same:
                     rec["scaling_efficiency_vs_committed_n1"] = {"value": min(per_rank) / ref1["per_chain"], "n1_per_chain": ref1["per_chain"],
                                                                  "definition": "slowest rank's per-chain rate / per-chain rate of profiles/bench_n1_reference.json"}
+                else:
+                    rec["scaling_efficiency_vs_committed_n1"] = {"value": None, "status": "profiles/bench_n1_reference.json was made by other sources, another tree path or "
+                                                                 "another burn-in: refused (the driver computes the efficiency from its own N = 1 run)"}
             except (OSError, ValueError, KeyError):
                 pass
         if dt1_max is not None:
+            lf_win, lf_next = rec["config"]["n_leapfrog_per_step"], modes[0][1]
+            rec["config"]["stationarity"] = {
+                "n_leapfrog_per_step_timed_window": lf_win, "n_leapfrog_per_step_next_iterations": lf_next, "next_iterations": a.mode_iters,
+                "ratio": lf_win / lf_next if lf_next else None, "stationary": bool(lf_next and 0.8 <= lf_win / lf_next <= 1.25),
+                "rate_next_iterations_same_mode": a.mode_iters / modes[0][0],
+                "note": "the timed window and the chain's next iterations (hmc_mode 0, from the state the window left) must cost the same leapfrogs per "
+                        "iteration (within 20 %) for `value` to be a figure of the stationary regime"}
             rec["gradient_modes_same_iterations"] = {
                 "iterations": a.mode_iters, "from": "one saved state (s4b_get_state / s4b_set_state), sampling phase, rank 0's chain",
                 "hmc_mode0": {"iters_per_sec": a.mode_iters / modes[0][0], "ms_per_step": 1e3 * modes[0][0] / a.mode_iters, "n_leapfrog_per_step": modes[0][1]},

@@ -45,7 +45,7 @@ typedef struct {
   int32_t keep_trees;   /* control@keepTrees                                          */
   int32_t node_capacity;/* 0 = default (256): max node slots per tree on the device   */
   double base, power;   /* cgm(power = 2, base = 0.95)                                */
-  double k;             /* normal(k = 2)                                              */
+  double k;             /* normal(k = 2): the fixed k, or the value a modeled k starts from */
   double node_scale;    /* model@node.scale: 0.5 continuous, 3.0 binary (:477-479)    */
   double birth_or_death_prob, swap_prob, change_prob, birth_prob; /* dbarts: .5 .1 .4 .5 */
   const double* split_probs; /* cgm(split.probs = ): NULL (predictors equally likely) or one positive weight per predictor, any scale:
@@ -55,6 +55,13 @@ typedef struct {
   int32_t use_quantiles;     /* dbartsControl(useQuantiles = ) through bart_args (R/stan4bart_fit.R:440-444): 0 uniform cut points
                               * between the column extremes, 1 cut points from the distinct values (n_cuts is then a maximum)    */
   int32_t reserved;
+  /* normal(k = chi(degreesOfFreedom, scale)) — reference R/stan4bart.R:202 ("allow calls like bart_args = list(k = chi(2, Inf))"),
+   * R/stan4bart_fit.R:460-465, tests/testthat/test-09-bartArgs.R:32; model@node.hyperprior, `kPrior->isFixed` src/init.cpp:272,731.
+   * k_hyper_df <= 0: k is fixed (`k` above).  k_hyper_df > 0: k is a parameter with prior density k^(df - 1) exp(-k^2 / (2 scale^2))
+   * (k_hyper_scale may be +Inf) that is redrawn once per sweep, after the trees (and the latents of a binary response), from its
+   * conditional given the leaf values (k^2 ~ Gamma((df + #leaves) / 2, rate (T sum mu^2 / node_scale^2 + 1 / scale^2) / 2), one rgamma from
+   * R's stream); its draws come back in s4b_results.bart_k. */
+  double k_hyper_df, k_hyper_scale;
 } s4b_bart_control;
 
 /* dbartsData slots (R/lme4_functions.R:176, R/stan4bart_fit.R:449-451) */
@@ -144,6 +151,8 @@ typedef struct {
   double* bart_train;    /* n x num_samples        */
   double* bart_test;     /* n_test x num_samples   */
   int32_t* bart_varcount;/* p x num_samples        */
+  double* bart_k;        /* num_samples: the draws of a modeled k (k_hyper_df > 0; reference result element "k", src/bart_util.cpp:17-26,60-64,75-76);
+                          * with a fixed k the buffer, if given, is filled with that value */
 } s4b_results;
 
 /* R's generator state as 625 words {mti, mt[0..623]} == .Random.seed[2:626]
@@ -257,7 +266,7 @@ typedef struct {
   uint32_t magic, version;   /* S4B_STATE_MAGIC, 1 */
   int64_t n;
   int32_t n_trees, num_unconstrained, is_binary, p;
-  int64_t reserved[2];
+  int64_t reserved[2];       /* [0]: bit pattern of the current k (a double) when k is modeled, else 0 */
 } s4b_state_header;
 int S4B_FN(get_state)(s4b_sampler* s, void* buf, int64_t cap, int64_t* size);
 int S4B_FN(set_state)(s4b_sampler* s, const void* buf, int64_t size);
@@ -293,6 +302,11 @@ int S4B_FN(get_fused_stats)(s4b_sampler* s, int64_t out[2]);
 /* persistent tree path only (zeros otherwise): out = {sweeps run by k_sweep, of which handed over to k_step launches part-way because a
  * tree outgrew the 64 node slots of the wave-register control path} since creation */
 int S4B_FN(get_sweep_stats)(s4b_sampler* s, int64_t out[2]);
+/* persistent tree path only (zero otherwise): persistent launches that found the device shared (not every workgroup of the launch became
+ * resident within 200 us: somebody else's kernels held compute units).  Such a launch changes nothing; its sweep ran as k_step launches and
+ * so do the next 16, 32, ... sweeps before the persistent launch is tried again.  (The reference's chain fan-out starts one worker process
+ * per chain, R/stan4bart_fit.R:498-533: on a box with fewer GPUs than chains those processes share devices.) */
+int S4B_FN(get_sweep_busy)(s4b_sampler* s, int64_t* out);
 /* extension: how the Stan block evaluates the O(N) part of the log density (stan_control.hmc_mode): 0 = sufficient statistics
  * gathered once per Gibbs iteration, 1 = one device evaluation per leapfrog (the reference's cost model).  A sampler created
  * with mode 0 may be switched to 1 and back between runs (same posterior, same draws up to rounding); one created with mode 1

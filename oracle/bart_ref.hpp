@@ -31,7 +31,11 @@ struct BartConfig {
   int thin = 1;              // dbartsControl n.thin = skip.bart (R/stan4bart_fit.R:438)
   bool binary = false;
   double base = 0.95, power = 2.0;
-  double k = 2.0;
+  double k = 2.0;            // normal(k = ): fixed, or the value a modeled k starts from
+  // normal(k = chi(degreesOfFreedom, scale)) (reference R/stan4bart.R:202, tests/testthat/test-09-bartArgs.R:32; src/init.cpp:272,731
+  // kPrior->isFixed): kDf > 0 makes k a parameter with prior density  p(k) ~ k^(df - 1) exp(-k^2 / (2 scale^2))  (scale = Inf: the second
+  // factor is 1) that dbarts redraws once per sweep.  PARITY UNPINNED like the rest of this file.
+  double kDf = 0.0, kScale = INFINITY;
   double nodeScale = 0.5;    // 0.5 continuous / 3.0 binary (R/stan4bart_fit.R:477-479)
   double birthOrDeathProb = 0.5, swapProb = 0.1, changeProb = 0.4, birthProb = 0.5;
   // cgm(split.probs = ) (reference R/stan4bart_fit.R:466-475; tests/testthat/test-09-bartArgs.R:20): empty = predictors
@@ -71,6 +75,7 @@ struct Node {
 
 struct BartResults {
   double sigma;
+  double k;
   std::vector<double> train, test;
   std::vector<uint32_t> varcount;
 };
@@ -202,7 +207,9 @@ class BartFit {
       }
       if (cfg.binary) sampleProbitLatents();
       // residual variance prior is fixed(1) (R/stan4bart_fit.R:456): sigma is left untouched
+      if (cfg.kDf > 0.0) drawK();
     }
+    res.k = cfg.k;
     res.sigma = cfg.binary ? 1.0 : sigma * scaleRange;
     res.train.resize(n);
     res.test.resize(nTest);
@@ -215,6 +222,26 @@ class BartFit {
     }
     res.varcount.assign(p, 0);
     for (Node* t : trees) countVars(t, res.varcount);
+  }
+
+  // dbarts' chi hyperprior step for k (restated): the leaf values of all trees are N(0, (nodeScale / (k sqrt(T)))^2) a priori, so given the
+  // m bottom nodes' values  k^2 ~ Gamma(shape = (df + m) / 2, rate = (T sum mu^2 / nodeScale^2 + 1 / scale^2) / 2);  one rgamma from R's
+  // stream, after the trees (and the latents of a binary response) of the sweep.  Leaf values as dbarts recovers them from the fits: a
+  // bottom node without observations counts with value 0.  A zero rate (every value 0 and an infinite scale) leaves k as it is.
+  void drawK() {
+    double sumSq = 0.0; size_t m = 0;
+    for (int t = 0; t < cfg.numTrees; ++t) {
+      std::vector<Node*> bottom; fillBottom(trees[t], bottom);
+      const double* fits = &treeFits[(size_t)t * n];
+      double treeSq = 0.0;
+      for (Node* b : bottom) { ++m; if (!b->obs.empty()) { const double mu = fits[b->obs[0]]; treeSq += mu * mu; } }
+      sumSq += treeSq;
+    }
+    const double invScale2 = std::isinf(cfg.kScale) ? 0.0 : 1.0 / (cfg.kScale * cfg.kScale);
+    const double rate = 0.5 * ((double)cfg.numTrees * sumSq / (cfg.nodeScale * cfg.nodeScale) + invScale2);
+    const double shape = 0.5 * (cfg.kDf + (double)m);
+    if (!(rate > 0.0)) return;
+    cfg.k = std::sqrt(rng->rgamma(shape, 1.0 / rate));
   }
 
   // dbarts storeLatents (reference src/init.cpp:289,845)

@@ -121,6 +121,11 @@ int orc_create(const s4b_bart_control* bc, const s4b_bart_data* bd, const s4b_st
     BartConfig cfg;
     cfg.numTrees = bc->n_trees; cfg.thin = bc->n_thin > 0 ? bc->n_thin : 1; cfg.binary = s.binary;
     cfg.base = bc->base; cfg.power = bc->power; cfg.k = bc->k; cfg.nodeScale = bc->node_scale;
+    if (bc->k_hyper_df > 0.0) {       // normal(k = chi(df, scale)): k is redrawn every sweep (bart_ref.hpp drawK)
+      if (!(bc->k_hyper_scale > 0.0)) throw std::invalid_argument("k_hyper_scale must be positive (or +Inf)");
+      if (!(bc->k > 0.0)) throw std::invalid_argument("k must be positive");
+      cfg.kDf = bc->k_hyper_df; cfg.kScale = bc->k_hyper_scale;
+    }
     cfg.birthOrDeathProb = bc->birth_or_death_prob; cfg.swapProb = bc->swap_prob; cfg.changeProb = bc->change_prob; cfg.birthProb = bc->birth_prob;
     if (bc->split_probs) cfg.splitProbs.assign(bc->split_probs, bc->split_probs + bd->p);
     cfg.useQuantiles = bc->use_quantiles != 0;
@@ -209,6 +214,7 @@ int orc_run(s4b_sampler* sp, int32_t numIter, int32_t isWarmup, int32_t resultsT
         if (s.binary) { s.bart->getLatents(s.bartLatents.data()); s.model->set_response(s.bartLatents.data()); }
         if (out) {
           if (out->bart_sigma) out->bart_sigma[slot] = res.sigma;
+          if (out->bart_k) out->bart_k[slot] = res.k;
           if (out->bart_train) std::memcpy(out->bart_train + slot * n, res.train.data(), n * sizeof(double));
           if (out->bart_test && nTest) std::memcpy(out->bart_test + slot * nTest, res.test.data(), nTest * sizeof(double));
           if (out->bart_varcount) for (size_t j = 0; j < p; ++j) out->bart_varcount[slot * p + j] = (int32_t)res.varcount[j];
@@ -448,6 +454,7 @@ int orc_get_state(s4b_sampler* s, void* buf, int64_t cap, int64_t* size) {
     Blob o;
     s4b_state_header hd; std::memset(&hd, 0, sizeof(hd));
     hd.magic = S4B_STATE_MAGIC; hd.version = 1; hd.n = (int64_t)n; hd.n_trees = bf.cfg.numTrees; hd.num_unconstrained = D; hd.is_binary = s->binary ? 1 : 0; hd.p = (int32_t)bf.p;
+    if (bf.cfg.kDf > 0.0) std::memcpy(&hd.reserved[0], &bf.cfg.k, 8);      // (the current value of a modeled k)
     o.one(hd);
     o.put(ns.cont_params.data(), (size_t)D); o.put(ns.inv_metric.data(), (size_t)D); o.put(ns.wf_m.data(), (size_t)D); o.put(ns.wf_m2.data(), (size_t)D);
     const double sc6[6] = {ns.nom_epsilon, ns.sa_mu, ns.sa_counter, ns.sa_s_bar, ns.sa_x_bar, ns.wf_n};
@@ -486,6 +493,11 @@ int orc_set_state(s4b_sampler* s, const void* buf, int64_t size) {
     if (hd.magic != S4B_STATE_MAGIC || hd.version != 1u) throw std::invalid_argument("not a stan4bart sampler state");
     if (hd.n != (int64_t)n || hd.n_trees != bf.cfg.numTrees || hd.num_unconstrained != D || (hd.is_binary != 0) != s->binary || hd.p != (int32_t)bf.p)
       throw std::invalid_argument("sampler state: dimensions do not match this sampler");
+    if (bf.cfg.kDf > 0.0) {
+      double kk; std::memcpy(&kk, &hd.reserved[0], 8);
+      if (!(kk > 0.0) || !std::isfinite(kk)) throw std::invalid_argument("sampler state: k must be positive and finite");
+      bf.cfg.k = kk;
+    }
     in.get(ns.cont_params.data(), (size_t)D); in.get(ns.inv_metric.data(), (size_t)D); in.get(ns.wf_m.data(), (size_t)D); in.get(ns.wf_m2.data(), (size_t)D);
     double sc6[6]; in.get(sc6, 6);
     ns.nom_epsilon = sc6[0]; ns.sa_mu = sc6[1]; ns.sa_counter = sc6[2]; ns.sa_s_bar = sc6[3]; ns.sa_x_bar = sc6[4]; ns.wf_n = sc6[5];
@@ -544,6 +556,14 @@ void orc_test_boost_draws(uint32_t seed, uint32_t chain, int32_t n_u, double* u,
   for (int i = 0; i < n_norm; ++i) norm[i] = boost_normal(e);
 }
 // log density + gradient of the Stan model at an arbitrary unconstrained point
+// test hook: `count` draws of rgamma(shape, scale) from an R generator seeded like set.seed(seed) (tests/test_bart_args.py)
+int orc_test_rgamma(uint32_t seed, double shape, double scale, int32_t count, double* out) {
+  try {
+    RRng r; r.set_seed(seed);
+    for (int32_t i = 0; i < count; ++i) out[i] = r.rgamma(shape, scale);
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
 int orc_test_log_prob_grad(s4b_sampler* s, const double* q, double* lp, double* grad) {
   std::vector<double> qv(q, q + s->model->D), g;
   *lp = s->model->log_prob_grad(qv, g);

@@ -100,6 +100,78 @@ struct RRng {
     return a + umin * q[0];
   }
 
+  // rgamma(a, scale) (nmath/rgamma.c: Ahrens & Dieter GD (1982) for a >= 1, GS (1974) for a < 1), the generator behind dbarts'
+  // ext_rng_simulateGamma when the chain draws from R's native stream.  The static caches of the C source only save
+  // recomputation; every call here recomputes what depends on `a`.
+  double rgamma(double a, double scale) {
+    const double sqrt32 = 5.656854, exp_m1 = 0.36787944117144233;
+    const double q1 = 0.04166669, q2 = 0.02083148, q3 = 0.00801191, q4 = 0.00144121, q5 = -7.388e-5, q6 = 2.4511e-4, q7 = 2.424e-4;
+    const double a1 = 0.3333333, a2 = -0.250003, a3 = 0.2000062, a4 = -0.1662921, a5 = 0.1423657, a6 = -0.1367177, a7 = 0.1233795;
+    if (std::isnan(a) || std::isnan(scale)) return NAN;
+    if (a <= 0.0 || scale <= 0.0) { if (scale == 0.0 || a == 0.0) return 0.0; return NAN; }
+    if (!std::isfinite(a) || !std::isfinite(scale)) return INFINITY;
+    double e, p, q, r, t, u, v, w, x, ret_val;
+    if (a < 1) {  // GS
+      e = 1.0 + exp_m1 * a;
+      for (;;) {
+        p = e * unif_rand();
+        if (p >= 1.0) {
+          x = -std::log((e - p) / a);
+          if (exp_rand() >= (1.0 - a) * std::log(x)) break;
+        } else {
+          x = std::exp(std::log(p) / a);
+          if (exp_rand() >= x) break;
+        }
+      }
+      return scale * x;
+    }
+    // Step 1
+    const double s2 = a - 0.5, s = std::sqrt(s2), d = sqrt32 - s * 12;
+    // Step 2: immediate acceptance
+    t = norm_rand();
+    x = s + 0.5 * t;
+    ret_val = x * x;
+    if (t >= 0) return scale * ret_val;
+    // Step 3: squeeze acceptance
+    u = unif_rand();
+    if (d * u <= t * t * t) return scale * ret_val;
+    // Step 4
+    r = 1 / a;
+    const double q0 = ((((((q7 * r + q6) * r + q5) * r + q4) * r + q3) * r + q2) * r + q1) * r;
+    double b, si, c;
+    if (a <= 3.686) { b = 0.463 + s + 0.178 * s2; si = 1.235; c = 0.195 / s - 0.079 + 0.16 * s; }
+    else if (a <= 13.022) { b = 1.654 + 0.0076 * s2; si = 1.68 / s + 0.275; c = 0.062 / s + 0.024; }
+    else { b = 1.77; si = 0.75; c = 0.1515 / s; }
+    // Step 5-7: quotient test
+    if (x > 0.0) {
+      v = t / (s + s);
+      if (std::fabs(v) <= 0.25) q = q0 + 0.5 * t * t * ((((((a7 * v + a6) * v + a5) * v + a4) * v + a3) * v + a2) * v + a1) * v;
+      else q = q0 - s * t + 0.25 * t * t + (s2 + s2) * std::log(1.0 + v);
+      if (std::log(1.0 - u) <= q) return scale * ret_val;
+    }
+    for (;;) {
+      // Step 8: double exponential sample
+      e = exp_rand();
+      u = unif_rand();
+      u = u + u - 1.0;
+      if (u < 0.0) t = b - si * e; else t = b + si * e;
+      // Step 9
+      if (t >= -0.71874483771719) {
+        // Step 10
+        v = t / (s + s);
+        if (std::fabs(v) <= 0.25) q = q0 + 0.5 * t * t * ((((((a7 * v + a6) * v + a5) * v + a4) * v + a3) * v + a2) * v + a1) * v;
+        else q = q0 - s * t + 0.25 * t * t + (s2 + s2) * std::log(1.0 + v);
+        // Step 11: hat acceptance
+        if (q > 0.0) {
+          w = std::expm1(q);
+          if (c * std::fabs(u) <= w * std::exp(e - 0.5 * t * t)) break;
+        }
+      }
+    }
+    x = s + 0.5 * t;
+    return scale * x * x;
+  }
+
   // R_unif_index(dn), sample.kind = "Rejection" (R >= 3.6)
   double unif_index(double dn) {
     if (dn <= 0) return 0.0;

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <set>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "stan4bart_amd.h"
@@ -77,7 +78,7 @@ void write_r_rng(const uint32_t state[S4B_R_RNG_WORDS]) {
 struct Sampler {                 // reference `Sampler`, src/init.cpp:124-173
   s4b_sampler* h = nullptr;
   int64_t numPars = 0, n = 0, nTest = 0, p = 0, nTrees = 0;
-  bool keepFits = true, keepTrees = false; int verbose = 0, refresh = 200;
+  bool keepFits = true, keepTrees = false, kModeled = false; int verbose = 0, refresh = 200;
   SEXP callback = R_NilValue, callbackEnv = R_NilValue;
   std::vector<std::string> parNames;
   // per run(): collected callback results
@@ -237,11 +238,18 @@ void unpack_bart(SEXP control, SEXP data, SEXP model, s4b_bart_control& bc, s4b_
   bc.power = Rf_asReal(slot(treePrior, "power")); bc.base = Rf_asReal(slot(treePrior, "base"));
   SEXP nodePrior = slot(model, "node.prior");
   bc.k = has_slot(nodePrior, "k") ? real_or(slot(nodePrior, "k"), 2.0) : 2.0;
-  // a hyperprior on k (bart_args$k = chi(...), R/stan4bart_fit.R:460-465: model@node.hyperprior is then not a fixed value) is
-  // not sampled on this path: refuse it rather than silently fixing k
+  // a hyperprior on k (bart_args$k = chi(df, scale), R/stan4bart_fit.R:460-465; R/stan4bart.R:202): model@node.hyperprior is then a
+  // dbartsChiHyperprior(degreesOfFreedom, scale) instead of a fixed value — k is sampled (s4b_bart_control.k_hyper_df / k_hyper_scale) and
+  // starts from dbarts' default 2
+  bc.k_hyper_df = 0.0; bc.k_hyper_scale = std::numeric_limits<double>::infinity();
   if (has_slot(model, "node.hyperprior")) {
     SEXP hp = slot(model, "node.hyperprior");
-    if (!Rf_isNull(hp) && has_slot(hp, "degreesOfFreedom")) Rf_error("a hyperprior on k (chi) is not supported by stan4bart_amd: pass a number as bart_args$k");
+    if (!Rf_isNull(hp) && has_slot(hp, "degreesOfFreedom")) {
+      bc.k_hyper_df = Rf_asReal(slot(hp, "degreesOfFreedom"));
+      bc.k_hyper_scale = has_slot(hp, "scale") ? Rf_asReal(slot(hp, "scale")) : std::numeric_limits<double>::infinity();
+      if (!(bc.k_hyper_df > 0.0) || !(bc.k_hyper_scale > 0.0)) Rf_error("node.hyperprior: degreesOfFreedom and scale must be positive");
+      bc.k = 2.0;
+    } else if (!Rf_isNull(hp) && has_slot(hp, "k")) bc.k = real_or(slot(hp, "k"), bc.k);      // dbartsFixedHyperprior(k)
   }
   // cgm(split.probs = ): tree.prior@splitProbabilities, one weight per predictor (numeric(0) = equally likely)
   if (has_slot(treePrior, "splitProbabilities")) {
@@ -311,7 +319,7 @@ static SEXP createSampler(SEXP bartControlExpr, SEXP bartDataExpr, SEXP bartMode
   if (!Rf_isNull(callbackEnv) && !Rf_isEnvironment(callbackEnv)) Rf_error("callbackEnv must be an environment or NULL");
 
   Sampler* s = new Sampler;
-  s->keepFits = cc.keep_fits != 0; s->keepTrees = bc.keep_trees != 0; s->verbose = cc.verbose; s->refresh = cc.refresh;
+  s->keepFits = cc.keep_fits != 0; s->keepTrees = bc.keep_trees != 0; s->kModeled = bc.k_hyper_df > 0.0; s->verbose = cc.verbose; s->refresh = cc.refresh;
   s->callback = callback; s->callbackEnv = callbackEnv;
   if (!Rf_isNull(callback)) { cc.callback = callback_trampoline; cc.callback_user = s; }
   uint32_t rng[S4B_R_RNG_WORDS];
@@ -366,15 +374,17 @@ static SEXP run(SEXP samplerExpr, SEXP numIterExpr, SEXP isWarmupExpr, SEXP resu
     Rf_setAttrib(stan, R_DimNamesSymbol, dimnames);
     out.stan = REAL(stan);
   }
-  if (s.keepFits && doBart) {   // list(sigma, train, test, varcount) (reference src/bart_util.cpp:13-81)
-    bart = PROTECT(Rf_allocVector(VECSXP, 4)); ++protectCount;
+  if (s.keepFits && doBart) {   // list(sigma, train, test, varcount[, k]) (reference src/bart_util.cpp:13-81: the fifth element only when k is modeled)
+    const int nb = s.kModeled ? 5 : 4;
+    bart = PROTECT(Rf_allocVector(VECSXP, nb)); ++protectCount;
     SEXP sigma = Rf_allocVector(REALSXP, S); SET_VECTOR_ELT(bart, 0, sigma);
     SEXP train = Rf_allocMatrix(REALSXP, (int)s.n, (int)S); SET_VECTOR_ELT(bart, 1, train);
     SEXP test = R_NilValue;
     if (s.nTest > 0) { test = Rf_allocMatrix(REALSXP, (int)s.nTest, (int)S); SET_VECTOR_ELT(bart, 2, test); }
     SEXP varcount = Rf_allocMatrix(INTSXP, (int)s.p, (int)S); SET_VECTOR_ELT(bart, 3, varcount);
-    SEXP nm = PROTECT(Rf_allocVector(STRSXP, 4)); ++protectCount;
+    SEXP nm = PROTECT(Rf_allocVector(STRSXP, nb)); ++protectCount;
     SET_STRING_ELT(nm, 0, Rf_mkChar("sigma")); SET_STRING_ELT(nm, 1, Rf_mkChar("train")); SET_STRING_ELT(nm, 2, Rf_mkChar("test")); SET_STRING_ELT(nm, 3, Rf_mkChar("varcount"));
+    if (s.kModeled) { SEXP kd = Rf_allocVector(REALSXP, S); SET_VECTOR_ELT(bart, 4, kd); SET_STRING_ELT(nm, 4, Rf_mkChar("k")); out.bart_k = REAL(kd); }
     Rf_setAttrib(bart, R_NamesSymbol, nm);
     out.bart_sigma = REAL(sigma); out.bart_train = REAL(train); out.bart_test = s.nTest > 0 ? REAL(test) : nullptr; out.bart_varcount = INTEGER(varcount);
   }

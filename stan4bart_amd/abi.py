@@ -24,7 +24,8 @@ class BartControl(C.Structure):
                 ("base", C.c_double), ("power", C.c_double), ("k", C.c_double), ("node_scale", C.c_double),
                 ("birth_or_death_prob", C.c_double), ("swap_prob", C.c_double),
                 ("change_prob", C.c_double), ("birth_prob", C.c_double),
-                ("split_probs", c_double_p), ("use_quantiles", C.c_int32), ("reserved", C.c_int32)]
+                ("split_probs", c_double_p), ("use_quantiles", C.c_int32), ("reserved", C.c_int32),
+                ("k_hyper_df", C.c_double), ("k_hyper_scale", C.c_double)]
 
 
 class BartData(C.Structure):
@@ -78,7 +79,7 @@ class CommonControl(C.Structure):
 
 class Results(C.Structure):
     _fields_ = [("stan", c_double_p), ("bart_sigma", c_double_p), ("bart_train", c_double_p),
-                ("bart_test", c_double_p), ("bart_varcount", c_int32_p)]
+                ("bart_test", c_double_p), ("bart_varcount", c_int32_p), ("bart_k", c_double_p)]
 
 
 def _dp(a: Optional[np.ndarray]):
@@ -115,6 +116,7 @@ class SamplerArgs:
     proposal_probs: Sequence[float] = (0.5, 0.1, 0.4, 0.5)
     split_probs: Optional[Sequence[float]] = None     # cgm(split.probs): one positive weight per BART predictor, or None (uniform)
     use_quantiles: bool = False                       # dbartsControl(useQuantiles): cut points from the distinct values
+    k_hyper: Optional[tuple] = None                   # normal(k = chi(degreesOfFreedom, scale)): (df, scale) -> k is sampled; `k` is where it starts
     # stan data
     X: Optional[np.ndarray] = None          # n x K (already centred)
     y: Optional[np.ndarray] = None
@@ -196,7 +198,10 @@ class Sampler:
         bc = BartControl(n_trees=a.n_trees, n_thin=a.n_thin, keep_trees=int(a.keep_trees),
                          node_capacity=a.node_capacity, base=a.base, power=a.power, k=a.k, node_scale=ns,
                          birth_or_death_prob=pp[0], swap_prob=pp[1], change_prob=pp[2], birth_prob=pp[3],
-                         use_quantiles=int(bool(a.use_quantiles)))
+                         use_quantiles=int(bool(a.use_quantiles)),
+                         k_hyper_df=0.0 if a.k_hyper is None else float(a.k_hyper[0]),
+                         k_hyper_scale=float("inf") if a.k_hyper is None else float(a.k_hyper[1]))
+        self.k_modeled = a.k_hyper is not None
         if a.split_probs is not None:
             sp = keep(_f64(np.asarray(a.split_probs, dtype=np.float64)))
             if sp.shape != (xb.shape[1],):
@@ -284,7 +289,7 @@ class Sampler:
             "get_leaf_assignment": [vp, i32, ip], "get_counters": [vp, C.POINTER(i64)], "get_nuts_stats": [vp, dp],
             "profile_sweep": [vp, i32, dp], "profile_leapfrog": [vp, i32, dp],
             "set_progress": [vp, PROGRESS, vp], "set_device_sharing": [vp, i32],
-            "set_tree_path": [vp, i32], "get_tree_path": [vp, ip], "get_fused_stats": [vp, C.POINTER(i64)], "get_sweep_stats": [vp, C.POINTER(i64)], "set_hmc_mode": [vp, i32], "get_hmc_mode": [vp, ip],
+            "set_tree_path": [vp, i32], "get_tree_path": [vp, ip], "get_fused_stats": [vp, C.POINTER(i64)], "get_sweep_stats": [vp, C.POINTER(i64)], "get_sweep_busy": [vp, C.POINTER(i64)], "set_hmc_mode": [vp, i32], "get_hmc_mode": [vp, ip],
         }
         for name, argtypes in sig.items():
             fn = getattr(self._lib, self._pfx + name, None)
@@ -325,8 +330,10 @@ class Sampler:
         train = np.zeros((self.n, S), order="F")
         test = np.zeros((self.n_test, S), order="F")
         varcount = np.zeros((self.p, S), dtype=np.int32, order="F")
+        kdraws = np.zeros(S)
         res = Results(stan=_dp(stan), bart_sigma=_dp(sigma), bart_train=_dp(train),
-                      bart_test=_dp(test) if self.n_test else None, bart_varcount=_ip(varcount))
+                      bart_test=_dp(test) if self.n_test else None, bart_varcount=_ip(varcount),
+                      bart_k=_dp(kdraws) if getattr(self, "k_modeled", False) else None)
         self.callback_results = []
         self._pending_exc = None
         rc = self._f("run")(self._h, num_iter, int(is_warmup), results_type, C.byref(res))
@@ -339,6 +346,8 @@ class Sampler:
             out["stan"] = stan
         if results_type in (0, 1):
             out["bart"] = dict(sigma=sigma, train=train, test=test, varcount=varcount)
+            if getattr(self, "k_modeled", False):        # the reference's fifth result element (src/bart_util.cpp:17-26,75-76): only when k is modeled
+                out["bart"]["k"] = kdraws
         if self._py_callback is not None:
             out["callback"] = list(self.callback_results)
         return out
@@ -485,6 +494,15 @@ class Sampler:
         out = (C.c_int64 * 2)()
         self._check(fn(self._h, out))
         return (int(out[0]), int(out[1]))
+
+    def get_sweep_busy(self) -> int:
+        """Persistent launches that found the device shared (roll call failed; their sweeps ran as k_step launches) since creation."""
+        fn = getattr(self._lib, self._pfx + "get_sweep_busy", None)
+        if fn is None:
+            return 0
+        out = C.c_int64(0)
+        self._check(fn(self._h, C.byref(out)))
+        return int(out.value)
 
     def set_trace(self, enable: bool):
         self._check(self._f("set_trace")(self._h, int(enable)))

@@ -115,6 +115,28 @@ S4B_HD inline StepTables step_tables(const BartArrays& a, int t) {
   return s;
 }
 
+// ---- the k hyperprior: normal(k = chi(df, scale)) (reference R/stan4bart.R:202, src/init.cpp:272,731; dbarts' step restated)
+// Given the leaf values of all trees — N(0, (nodeScale / (k sqrt(T)))^2) a priori — and the prior density k^(df - 1) exp(-k^2 / (2 scale^2)):
+//   k^2 ~ Gamma(shape = (df + m) / 2, rate = (T sum mu^2 / nodeScale^2 + 1 / scale^2) / 2),  m = number of bottom nodes of all trees
+// (a bottom node without observations has no value: it counts in m and adds nothing to the sum).  One rgamma from R's stream per sweep,
+// after the trees and — binary response — the latents.  A zero rate leaves k as it is.
+struct KHyper { double df, invScale2, nodeScale; };
+S4B_HD inline void k_hyper_tree_stats(const BartArrays& a, int t, double& sumSq, double& leaves) {
+  const size_t o = (size_t)t * (size_t)a.nc;
+  const int hwm = a.hwm[t];
+  double s = 0.0, m = 0.0;
+  for (int i = 0; i < hwm; ++i)
+    if (a.var[o + i] == NODE_LEAF) { m += 1.0; if (a.cnt[o + i] > 0) { const double v = a.mu[o + i]; s += v * v; } }
+  sumSq = s; leaves = m;
+}
+template <class RNG> S4B_HD inline double k_hyper_draw(RNG* rng, const KHyper& h, int T, double sumSq, double leaves, double kOld) {
+  const double rate = 0.5 * ((double)T * sumSq / (h.nodeScale * h.nodeScale) + h.invScale2);
+  const double shape = 0.5 * (h.df + leaves);
+  if (!(rate > 0.0)) return kOld;
+  return sqrt(r_gamma(rng, shape, 1.0 / rate));
+}
+S4B_HD inline double leaf_precision(double k, int T, double nodeScale) { const double sd = nodeScale / (k * sqrt((double)T)); return 1.0 / (sd * sd); }
+
 // the control steps straight on the global arrays (host emulation of the device layer; also the device
 // fallback when a tree has more node slots than the wave-register path handles)
 S4B_HD inline void propose_step(const BartArrays& a, int t) {

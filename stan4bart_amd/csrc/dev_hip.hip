@@ -1043,6 +1043,24 @@ __global__ void k_scale(BartArrays a, StanArrays s, int update, int gridUsed) {
   }
 }
 
+// The k hyperprior's step (dev_common.hpp k_hyper_*): one workgroup; thread i sums the squared leaf values of trees i, i + 256, ..., thread 0
+// adds the 256 partial sums in index order and draws k from R's stream where the sweep (and the latents) left it.  out (host-mapped):
+// {k, leaf prior precision for that k} — the host puts the precision into the kernel arguments of the next sweep.
+__global__ __launch_bounds__(256) void k_draw_k(BartArrays a, KHyper h, double kOld, double* out) {
+  __shared__ double ss[256], mm[256];
+  double s = 0.0, m = 0.0;
+  for (int t = threadIdx.x; t < a.T; t += 256) { double s1, m1; k_hyper_tree_stats(a, t, s1, m1); s += s1; m += m1; }
+  ss[threadIdx.x] = s; mm[threadIdx.x] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double S = 0.0, M = 0.0;
+    for (int i = 0; i < 256; ++i) { S += ss[i]; M += mm[i]; }
+    const double k = k_hyper_draw(a.rng, h, a.T, S, M, kOld);
+    out[0] = k; out[1] = leaf_precision(k, a.T, h.nodeScale);
+    __threadfence_system();
+  }
+}
+
 __global__ void k_set_sigma(BartArrays a, double sigmaData) {
   a.scale->sigmaData = sigmaData; a.scale->sigma = sigmaData / a.scale->range;
 }
@@ -1894,10 +1912,26 @@ class DevHip {
     for (void* p : allocs_) (void)hipFree(p);
     if (pinned_) (void)hipHostFree(pinned_);
     if (pinnedAcc_) (void)hipHostFree(pinnedAcc_);
+    if (kOut_) (void)hipHostFree(kOut_);
     if (stream_) (void)hipStreamDestroy(stream_);
     if (evStart_) { (void)hipEventDestroy(evStart_); (void)hipEventDestroy(evStop_); }
   }
   DevHip(const DevHip&) = delete;
+  // ---- k hyperprior: k is redrawn after every sweep (k_draw_k) and the host waits for it — the leaf prior precision of the next sweep
+  // travels in the kernel arguments (no graph replay then: its kernel nodes would hold the precision of the sweep that was captured)
+  void set_k_hyper(double df, double scale, double nodeScale, double k0) {
+    kModeled_ = true; kh_.df = df; kh_.invScale2 = std::isinf(scale) ? 0.0 : 1.0 / (scale * scale); kh_.nodeScale = nodeScale; kCur_ = k0;
+    useGraph_ = false;
+    if (!kOut_) { HIP_OK(hipHostMalloc(&kOut_, 64, hipHostMallocCoherent | hipHostMallocMapped)); void* dp = nullptr; HIP_OK(hipHostGetDevicePointer(&dp, kOut_, 0)); kOutDev_ = (double*)dp; }
+  }
+  double k_current() const { return kCur_; }
+  void set_k(double k) { kCur_ = k; a_.model.leafPrec = leaf_precision(k, T_, kh_.nodeScale); }
+  void draw_k() {
+    hipLaunchKernelGGL(k_draw_k, dim3(1), dim3(256), 0, stream_, a_, kh_, kCur_, kOutDev_); ++launches_;
+    sync();
+    set_k(((volatile double*)kOut_)[0]);
+  }
+  bool kModeled_ = false; KHyper kh_{0, 0, 1}; double kCur_ = 2.0; double* kOut_ = nullptr; double* kOutDev_ = nullptr;
 
   // stored sampler: only a device, a stream and the predictor count (predict_stored needs nothing else)
   void init_stored(int device, int P) {
@@ -2035,7 +2069,7 @@ class DevHip {
         if (getenv("S4B_NOSOLO")) sweepGrid_ = a.gridF;
 #endif
         if (sweepOk_) {
-          xbuf_ = zalloc<unsigned long long>((size_t)2 * XC_RING * XC_BUF_WORDS);   // two rings: a launch uses one and clears the other for the next launch
+          xbuf_ = zalloc<unsigned long long>((size_t)2 * (XC_RING * XC_BUF_WORDS + XC_ROLL_WORDS));   // two rings (+ the words of the roll call behind each): a launch uses one and clears the other for the next launch
           HIP_OK(hipHostMalloc(&sweepStatus_, 64, hipHostMallocCoherent | hipHostMallocMapped));
           sweepStatus_[0] = -1;
           { void* dp = nullptr; HIP_OK(hipHostGetDevicePointer(&dp, sweepStatus_, 0)); sweepStatusDev_ = (int32_t*)dp; }
@@ -2265,30 +2299,45 @@ class DevHip {
   // kept out this way (s4b_set_device_sharing; the bounded waits turn such a collision into an error, not a hang).
   static std::mutex& sweep_mutex(int device) { static std::mutex m[64]; return m[device & 63]; }
   std::unique_lock<std::mutex> sweepLock_;
+  // (scope guard: whatever ends a block that launched a persistent sweep — its normal end or an exception on the way — gives the device's turn back)
+  struct TurnGuard { DevHip& d; explicit TurnGuard(DevHip& dd) : d(dd) {} ~TurnGuard() { if (d.sweepLock_.owns_lock()) d.sweepLock_.unlock(); }
+                     TurnGuard(const TurnGuard&) = delete; TurnGuard& operator=(const TurnGuard&) = delete; };
+  // The device was busy at the last persistent launch (its roll call failed: another process's kernels held compute units): the next
+  // sweepBackoff_ sweeps run as k_step launches, then the persistent launch is tried again; every further failure doubles the pause.
+  int64_t sweepBusyUntil_ = 0, sweepBusy_ = 0; int sweepBackoff_ = 16;
+  bool persistent_now() const { return sweepCount_ >= sweepBusyUntil_; }
   void sweep_persistent_launch() {
     if (sweepLock_.owns_lock()) sweepLock_.unlock();      // (a previous launch whose end an exception kept us from seeing)
     sweepLock_ = std::unique_lock<std::mutex>(sweep_mutex(device_));
     for (int i = 0; i < 16; ++i) sweepStatus_[i] = 0;
     sweepStatus_[0] = -1;
     hipLaunchKernelGGL(k_sweep, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
-    HIP_OK(hipGetLastError());
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { sweepLock_.unlock(); HIP_OK(e); }
   }
   SweepArgs sweep_args() {     // (the exchange ring of this launch, the one it clears for the next launch)
-    unsigned long long* cur = xbuf_ + (size_t)xbufParity_ * XC_RING * XC_BUF_WORDS;
-    unsigned long long* nxt = xbuf_ + (size_t)(1 - xbufParity_) * XC_RING * XC_BUF_WORDS;
+    unsigned long long* cur = xbuf_ + (size_t)xbufParity_ * (XC_RING * XC_BUF_WORDS + XC_ROLL_WORDS);
+    unsigned long long* nxt = xbuf_ + (size_t)(1 - xbufParity_) * (XC_RING * XC_BUF_WORDS + XC_ROLL_WORDS);
     xbufParity_ ^= 1;
     return SweepArgs{cur, sweepStatusDev_, nxt};
   }
   // the launch has ended (the caller waited for it or for something behind it on the stream): true = the sweep is complete, false = the
-  // rest of it was handed over and has just been queued as k_step launches
+  // rest of it (or all of it) has just been queued as k_step launches
   bool sweep_persistent_finish() {
     if (sweepLock_.owns_lock()) sweepLock_.unlock();
     const int st = sweepStatus_[0];
     ++sweepCount_;
-    if (st == T_ + 1) return true;
+    if (st == T_ + 1) { if (sweepBackoff_ > 16 && sweepCount_ > sweepBusyUntil_ + 64) sweepBackoff_ = 16; return true; }
+    if (st == -2) {       // roll call failed: the device is shared right now; nothing of the chain was touched
+      ++sweepBusy_;
+      sweepBusyUntil_ = sweepCount_ + sweepBackoff_;
+      sweepBackoff_ = std::min(sweepBackoff_ * 2, 4096);
+      sweep_fused_or_two_one();
+      return false;
+    }
     if (st < 0 || st > T_ + 1) {
       int32_t e = 0; (void)hipMemcpy(&e, a_.errFlag, 4, hipMemcpyDeviceToHost);
-      throw std::runtime_error("persistent tree sweep: the launch did not complete (a workgroup timed out waiting for the others — is the device shared?); status " +
+      throw std::runtime_error("persistent tree sweep: the launch did not complete (a workgroup timed out waiting for the others); status " +
                                std::to_string(st) + ", device error word " + std::to_string(e) + ", first wait that gave up: dev_sweep.inc:" + std::to_string(sweepStatus_[1])
 #ifdef S4B_TUNING
                                + " | per workgroup (needBig << 24 | paGo << 8 | bailStep): " + std::to_string(sweepStatus_[2]) + " " + std::to_string(sweepStatus_[3]) + " " + std::to_string(sweepStatus_[4]) + " grid " + std::to_string(a_.gridF) + " tickets " + std::to_string(sweepStatus_[8]) + " " + std::to_string(sweepStatus_[9]) + " tail stage " + std::to_string(sweepStatus_[12])
@@ -2301,27 +2350,42 @@ class DevHip {
     if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_));
     return false;
   }
+  void sweep_fused_or_two_one() { sweep_fused_one(); }      // (a sampler on the persistent path always has the fused launch: sweepOk_ implies fusedOk_)
   void sweep_persistent_one() {
+    if (!persistent_now()) { ++sweepCount_; sweep_fused_one(); return; }
+    TurnGuard turn(*this);
     sweep_persistent_launch();
-    const hipError_t e = hipStreamSynchronize(stream_);
-    if (e != hipSuccess && sweepLock_.owns_lock()) sweepLock_.unlock();
-    HIP_OK(e);
+    HIP_OK(hipStreamSynchronize(stream_));
     sweep_persistent_finish();
   }
   // The Gibbs iteration's sweep followed by the Stan block's inputs (sampler_core.hpp run()).  On the persistent path the host does not
   // wait for the sweep's status word before queueing the Stan kernels: it waits once, for their result, and looks at the status then.
-  // A sweep that was handed over (a tree outgrew the wave-register control path: rare) is finished and the Stan inputs are formed again —
-  // they only read the BART state and overwrite their own outputs.
+  // A sweep that was not finished by the launch (a tree outgrew the wave-register control path: rare; the device was shared: rarer) is
+  // finished with k_step launches and the Stan inputs are formed again — they only read the BART state and overwrite their own outputs;
+  // what the discarded first evaluation did to the host-side state of the fixed-point sums (scales, counters) is put back first.
   void sweep_and_stan_inputs(int thin, int mode, bool wantTrain, double* cX, double* cZ, double* s0, double* trainOut) {
-    if (path_ != PATH_SWEEP || binary_ || thin < 1) { sweep(thin); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); return; }
+    if (path_ != PATH_SWEEP || binary_ || thin < 1 || !persistent_now() || kModeled_) { sweep(thin); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); return; }
     for (int k = 0; k + 1 < thin; ++k) sweep_persistent_one();
+    if (!persistent_now()) { ++sweepCount_; sweep_fused_one(); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); return; }
+    TurnGuard turn(*this);
     sweep_persistent_launch();
-    try { stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); }
-    catch (...) { if (sweepLock_.owns_lock()) sweepLock_.unlock(); throw; }      // (never keep the device's turn across an error)
-    if (!sweep_persistent_finish()) stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut);
+    const FxHostState saved = fx_host_state();
+    stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut);
+    if (!sweep_persistent_finish()) { set_fx_host_state(saved); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); }
   }
+  struct FxHostState { int exp[3]; int64_t lastBad, evals, fallbacks; bool tiny; };
+  FxHostState fx_host_state() const { FxHostState f; for (int g = 0; g < 3; ++g) f.exp[g] = fxExp_[g]; f.lastBad = fxLastBad_; f.evals = fusedEvals_; f.fallbacks = fusedFallbacks_; f.tiny = fxTinyFail_; return f; }
+  void set_fx_host_state(const FxHostState& f) { for (int g = 0; g < 3; ++g) fxExp_[g] = f.exp[g]; fxLastBad_ = f.lastBad; fusedEvals_ = f.evals; fusedFallbacks_ = f.fallbacks; fxTinyFail_ = f.tiny; }
   void sweep_impl(int thin) {
     flush_hand_off();
+    if (kModeled_) {      // one sweep at a time: trees, latents, k — then the host knows the precision the next sweep's launches carry
+      for (int k = 0; k < thin; ++k) {
+        if (path_ == PATH_SWEEP) sweep_persistent_one(); else sweep_eager(1, false);
+        if (binary_) launch_latents();
+        draw_k();
+      }
+      return;
+    }
     if (path_ == PATH_SWEEP) {
       for (int k = 0; k < thin; ++k) { sweep_persistent_one(); if (binary_) launch_latents(); }
       return;
@@ -2531,6 +2595,7 @@ class DevHip {
       }
       const int st = sweepStatus_[0];
       ++sweepCount_;
+      if (st == -2) { ++sweepBusy_; sweep_fused_one(); if (binary_) launch_latents(); sync(); continue; }     // (roll call failed: the device is shared; not a sample of the persistent launch)
       if (st < 0 || st > T_ + 1) throw std::runtime_error("persistent tree sweep: the launch did not complete");
       if (st != T_ + 1) {
         ++sweepHandOvers_;
@@ -2566,6 +2631,7 @@ class DevHip {
       fprintf(stderr, "SWEEP image wave 1, propose() alone by move type (count, us): birth %llu %.2f, death %llu %.2f, swap %llu %.2f, change %llu %.2f; without a valid move %llu; from the start of the drawing step to propose() %.2f us\n",
               h[36], h[36] ? h[24] / (100.0 * h[36]) : 0.0, h[37], h[37] ? h[25] / (100.0 * h[37]) : 0.0, h[38], h[38] ? h[26] / (100.0 * h[38]) : 0.0, h[39], h[39] ? h[27] / (100.0 * h[39]) : 0.0, h[62],
               (h[36] + h[37] + h[38] + h[39]) ? h[63] / (100.0 * (h[36] + h[37] + h[38] + h[39])) : 0.0);
+      fprintf(stderr, "SWEEP bins per step (histogram 0..15+):"); for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", h[72 + i]); fprintf(stderr, "\n");
       fprintf(stderr, "SWEEP statistics phase: wave 5 accumulated %.2f, wave-reduced + slots written %.2f, barrier passed %.2f; wave 3 barrier passed %.2f\n", h[30] * k, h[31] * k, h[32] * k, h[33] * k); }
 #endif
     out[0] = cnt ? sum / cnt : 0.0; out[3] = cnt;
@@ -2785,6 +2851,7 @@ class DevHip {
   // the chain that was never interrupted: bit-identical, not just equal to 2^-67.
   void reset_fused_scales() { fxExp_[0] = fxExp_[1] = fxExp_[2] = 0; fxLastBad_ = -2; fxTinyFail_ = false; }
   void sweep_stats(int64_t out[2]) const { out[0] = sweepCount_; out[1] = sweepHandOvers_; }
+  int64_t sweep_busy() const { return sweepBusy_; }
 
   // HIP-event timing of the per-leapfrog O(N) sums (hmc_mode 1 path: e = e0 - X beta - Z b, |e|^2, X'e, Z'e) on the
   // sampler's stream.  out: [0] us per evaluation, kernels only; [1] us per evaluation including the result fetch;

@@ -183,6 +183,61 @@ template <class RNG> S4B_HD inline double r_exp(RNG* s) {
   return a + umin * q0;
 }
 
+// rgamma(shape, scale) from R's stream (nmath/rgamma.c; dbarts' gamma draws come from it when a chain uses R's native generator): used
+// once per sweep by the k hyperprior (k_draw_k).  shape >= 1: Ahrens & Dieter's GD — a (s, 1/2)-normal deviate squared, accepted at
+// once for t >= 0, by a squeeze, by the quotient test, else a double-exponential rejection loop; shape < 1: their GS.
+struct GammaQuotient {          // the parts of GD that depend on the shape only
+  double s2, s, q0, b, si, c;
+  S4B_HD explicit GammaQuotient(double a) {
+    s2 = a - 0.5; s = sqrt(s2);
+    const double r = 1 / a;
+    q0 = ((((((2.424e-4 * r + 2.4511e-4) * r + -7.388e-5) * r + 0.00144121) * r + 0.00801191) * r + 0.02083148) * r + 0.04166669) * r;
+    if (a <= 3.686) { b = 0.463 + s + 0.178 * s2; si = 1.235; c = 0.195 / s - 0.079 + 0.16 * s; }
+    else if (a <= 13.022) { b = 1.654 + 0.0076 * s2; si = 1.68 / s + 0.275; c = 0.062 / s + 0.024; }
+    else { b = 1.77; si = 0.75; c = 0.1515 / s; }
+  }
+  S4B_HD double q(double t) const {
+    const double v = t / (s + s);
+    if (fabs(v) <= 0.25)
+      return q0 + 0.5 * t * t * ((((((0.1233795 * v + -0.1367177) * v + 0.1423657) * v + -0.1662921) * v + 0.2000062) * v + -0.250003) * v + 0.3333333) * v;
+    return q0 - s * t + 0.25 * t * t + (s2 + s2) * log(1.0 + v);
+  }
+};
+template <class RNG> S4B_HD inline double r_gamma(RNG* g, double a, double scale) {
+  if (a != a || scale != scale) return a + scale;
+  if (a <= 0.0 || scale <= 0.0) return (scale == 0.0 || a == 0.0) ? 0.0 : (a - a) / (a - a);
+  if (a - a != 0.0 || scale - scale != 0.0) return scale > a ? scale : a;      // (an infinite argument: +Inf)
+  if (a < 1) {
+    const double e = 1.0 + 0.36787944117144233 * a;
+    double x;
+    for (;;) {
+      const double p = e * r_unif(g);
+      if (p >= 1.0) { x = -log((e - p) / a); if (r_exp(g) >= (1.0 - a) * log(x)) break; }
+      else { x = exp(log(p) / a); if (r_exp(g) >= x) break; }
+    }
+    return scale * x;
+  }
+  const GammaQuotient G(a);
+  double t = r_norm(g);
+  const double x0 = G.s + 0.5 * t, first = x0 * x0;
+  if (t >= 0) return scale * first;
+  double u = r_unif(g);
+  if ((5.656854 - G.s * 12) * u <= t * t * t) return scale * first;
+  if (x0 > 0.0 && log(1.0 - u) <= G.q(t)) return scale * first;
+  for (;;) {
+    const double e = r_exp(g);
+    u = r_unif(g);
+    u = u + u - 1.0;
+    t = u < 0.0 ? G.b - G.si * e : G.b + G.si * e;
+    if (t < -0.71874483771719) continue;
+    const double q = G.q(t);
+    if (q <= 0.0) continue;
+    if (G.c * fabs(u) <= expm1(q) * exp(e - 0.5 * t * t)) break;
+  }
+  const double x = G.s + 0.5 * t;
+  return scale * x * x;
+}
+
 // uniform integer in [lo, hi) the way dbarts' ext_rng does it: lo + (int64)(u * range)
 template <class RNG> S4B_HD inline int r_unif_int(RNG* s, int lo, int hi_excl) {
   return lo + (int)(r_unif(s) * (double)(hi_excl - lo));

@@ -194,7 +194,11 @@ class SamplerCore {
     }
     di.model.base = bc->base; di.model.power = bc->power;
     di.model.pBD = bc->birth_or_death_prob; di.model.pSwap = bc->swap_prob; di.model.pChange = bc->change_prob; di.model.pBirth = bc->birth_prob;
-    { double sd_mu = bc->node_scale / (bc->k * std::sqrt((double)T_)); di.model.leafPrec = 1.0 / (sd_mu * sd_mu); }
+    if (!(bc->k > 0.0) || !std::isfinite(bc->k)) throw std::invalid_argument("k must be positive and finite");
+    kModeled_ = bc->k_hyper_df > 0.0; kFixed_ = bc->k;
+    if (kModeled_ && !(bc->k_hyper_scale > 0.0)) throw std::invalid_argument("k_hyper_scale must be positive (or +Inf)");
+    if (kModeled_ && !std::isfinite(bc->k_hyper_df)) throw std::invalid_argument("k_hyper_df must be finite");
+    di.model.leafPrec = leaf_precision(bc->k, T_, bc->node_scale);
     {   // lookup tables of the tree prior, computed with the host libm (device decisions then use the same values)
       pgDepth_.resize(S4B_MAX_DEPTH); logPg_.resize(S4B_MAX_DEPTH); log1mPg_.resize(S4B_MAX_DEPTH);
       for (int d = 0; d < S4B_MAX_DEPTH; ++d) {
@@ -211,6 +215,7 @@ class SamplerCore {
     di.traceCap = 1 << 16;
     hostModelView_ = di.model; hostModelView_.numCuts = numCuts_.data();   // (table pointers are host pointers)
     dev_.init(di);
+    if (kModeled_) dev_.set_k_hyper(bc->k_hyper_df, bc->k_hyper_scale, bc->node_scale, bc->k);     // normal(k = chi(df, scale)): redrawn after every sweep
 
     // ---- Stan sampler: init + init_stepsize run against offset_ = 0 and the raw y (reference
     //      interruptable_sampler.hpp:150,175-176 happen before any BART fit exists)
@@ -305,6 +310,7 @@ class SamplerCore {
         if (nTest_ && emit && ((out && out->bart_test) || callback_)) dev_.test_fits(test.data());
         if (out && emit) {
           if (out->bart_sigma) out->bart_sigma[slot] = sigma_;
+          if (out->bart_k) out->bart_k[slot] = kModeled_ ? dev_.k_current() : kFixed_;
           if (out->bart_train) std::memcpy(out->bart_train + slot * n_, train.data(), n_ * sizeof(double));
           if (out->bart_test && nTest_) std::memcpy(out->bart_test + slot * nTest_, test.data(), nTest_ * sizeof(double));
           if (out->bart_varcount) var_counts(out->bart_varcount + slot * (size_t)P_);
@@ -483,6 +489,7 @@ class SamplerCore {
     auto put = [&](const void* src, size_t k) { if (k) std::memcpy(o, src, k); o += k; };
     s4b_state_header hd; std::memset(&hd, 0, sizeof(hd));
     hd.magic = S4B_STATE_MAGIC; hd.version = 1; hd.n = (int64_t)n_; hd.n_trees = T_; hd.num_unconstrained = D; hd.is_binary = binary_ ? 1 : 0; hd.p = P_;
+    if (kModeled_) { const double kk = dev_.k_current(); std::memcpy(&hd.reserved[0], &kk, 8); }
     put(&hd, sizeof(hd));
     Nuts::State ns; nuts_->get_state(ns);
     put(ns.q.data(), (size_t)D * 8); put(ns.inv_metric.data(), (size_t)D * 8); put(ns.wm.data(), (size_t)D * 8); put(ns.wm2.data(), (size_t)D * 8);
@@ -575,7 +582,13 @@ class SamplerCore {
       for (int i = 0; i < D && ok; ++i) ok = ns.inv_metric[(size_t)i] > 0.0;
       if (!ok || !(sc6[0] > 0.0)) throw std::invalid_argument("sampler state: non-finite value, non-positive step size or inverse metric");
     }
+    double kState = 0.0;
+    if (kModeled_) {
+      std::memcpy(&kState, &hd.reserved[0], 8);
+      if (!(kState > 0.0) || !std::isfinite(kState)) throw std::invalid_argument("sampler state: k must be positive and finite");
+    }
     // ---- commit
+    if (kModeled_) dev_.set_k(kState);
     nuts_->set_state(ns);
     dev_.reset_fused_scales();
     nuts_->current_row(row_.data());
@@ -874,7 +887,7 @@ class SamplerCore {
   std::vector<double> pgDepth_, logPg_, log1mPg_, logInt_;
   ModelView hostModelView_;
   std::unique_ptr<HostModel> model_; std::unique_ptr<Nuts> nuts_;
-  bool keepTrees_ = false;
+  bool keepTrees_ = false, kModeled_ = false; double kFixed_ = 2.0;
   std::vector<PackedNode> keptNodes_; std::vector<int64_t> keptTreeStart_; std::vector<double> keptScale_;
   std::vector<double> row_, cX_, cZ_, gram_, gramDense_; int gramLd_ = 0; std::vector<int> gramPtr_, gramCol_; double s0_ = 0, sigma_ = 1;
   long treeUpdates_ = 0;

@@ -163,12 +163,52 @@ def init_fit(y, Xc, groups, n, is_binary):
     return mu, 1.0
 
 
-def _fixed_k(k) -> float:
-    """bart_args$k: a number (normal(k), reference R/stan4bart_fit.R:460-465).  dbarts also takes a hyperprior call there (chi(...)):
-    sampling k is not part of this path — refuse it instead of silently fixing k."""
+def _k_prior(k):
+    """bart_args$k (reference R/stan4bart_fit.R:460-465 puts it into dbarts' ``normal(k = ...)``): a number — the fixed k — or a
+    hyperprior the way dbarts writes it, ``chi(degreesOfFreedom = 1.25, scale = Inf)`` (reference R/stan4bart.R:202,
+    tests/testthat/test-09-bartArgs.R:32): the string of the R call, ``{"chi": (df, scale)}`` / ``{"chi": {...}}``, or ``("chi", df, scale)``.
+    Returns (k where the chain starts, None | (df, scale)); a modeled k starts from dbarts' default 2."""
     if isinstance(k, (int, float, np.integer, np.floating)):
-        return float(k)
-    raise NotImplementedError("bart_args['k'] must be a number: a hyperprior on k (dbarts chi(degreesOfFreedom, scale)) is not sampled on this path")
+        return float(k), None
+    df, scale = 1.25, float("inf")          # dbarts' defaults of chi()
+
+    def num(x):
+        x = str(x).strip()
+        return float("inf") if x in ("Inf", "inf", "+Inf") else float(x)
+    if isinstance(k, str):
+        txt = k.replace(" ", "")
+        if not (txt.startswith("chi(") and txt.endswith(")")) and txt != "chi":
+            raise ValueError(f"bart_args['k']: {k!r} is neither a number nor a chi(degreesOfFreedom, scale) hyperprior")
+        pos = 0
+        for a in [x for x in txt[4:-1].split(",") if x] if txt != "chi" else []:
+            if "=" in a:
+                nm, v = a.split("=", 1)
+                if nm in ("degreesOfFreedom", "df"):
+                    df = num(v)
+                elif nm == "scale":
+                    scale = num(v)
+                else:
+                    raise ValueError(f"bart_args['k']: unknown argument {nm!r} of chi()")
+            else:
+                if pos == 0:
+                    df = num(a)
+                else:
+                    scale = num(a)
+                pos += 1
+    elif isinstance(k, dict) and set(k) == {"chi"}:
+        v = k["chi"]
+        if isinstance(v, dict):
+            df, scale = float(v.get("degreesOfFreedom", v.get("df", df))), float(v.get("scale", scale))
+        else:
+            v = tuple(v)
+            df, scale = (float(v[0]) if len(v) > 0 else df), (float(v[1]) if len(v) > 1 else scale)
+    elif isinstance(k, (tuple, list)) and len(k) >= 1 and k[0] == "chi":
+        df, scale = (float(k[1]) if len(k) > 1 else df), (float(k[2]) if len(k) > 2 else scale)
+    else:
+        raise ValueError(f"bart_args['k']: {k!r} is neither a number nor a chi(degreesOfFreedom, scale) hyperprior")
+    if not (df > 0 and np.isfinite(df)) or not scale > 0:
+        raise ValueError("chi(degreesOfFreedom, scale): both must be positive (scale may be Inf)")
+    return 2.0, (df, scale)
 
 
 def _split_probs(sp, p: int, names=None):
@@ -273,7 +313,7 @@ def make_sampler_args(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_tes
         x_bart=np.asarray(x_bart, dtype=np.float64), x_test=x_test,
         n_trees=int(bart_args.get("n.trees", 75)), n_cuts=bart_args.get("n.cuts", 100), n_thin=skip_bart,
         base=float(bart_args.get("base", 0.95)), power=float(bart_args.get("power", 2.0)),
-        k=_fixed_k(bart_args.get("k", 2.0)), keep_trees=bool(bart_args.get("keepTrees", False)),
+        k=_k_prior(bart_args.get("k", 2.0))[0], k_hyper=_k_prior(bart_args.get("k", 2.0))[1], keep_trees=bool(bart_args.get("keepTrees", False)),
         split_probs=_split_probs(bart_args.get("split.probs"), np.asarray(x_bart).shape[1], bart_args.get("predictor.names")),
         use_quantiles=bool(bart_args.get("useQuantiles", False)),
         node_scale=3.0 if is_binary else 0.5,

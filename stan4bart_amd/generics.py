@@ -20,7 +20,7 @@ from .fit import GroupTerm, chain_seeds, hip_sampler_factory, make_sampler_args,
 from .rcompat import RRng
 
 INT_MAX = 2147483647
-EXTRACT_TYPES = ("ev", "ppd", "fixef", "indiv.fixef", "ranef", "indiv.ranef", "indiv.bart", "sigma", "Sigma", "varcount",
+EXTRACT_TYPES = ("ev", "ppd", "fixef", "indiv.fixef", "ranef", "indiv.ranef", "indiv.bart", "sigma", "Sigma", "k", "varcount",
                  "stan", "trees", "callback")
 
 
@@ -72,6 +72,7 @@ class Stan4bartFit:
     trees: Optional[list] = None
     callback: Optional[np.ndarray] = None   # [len(result), iterations, chains]
     weights: Optional[np.ndarray] = None    # observation weights of the training sample
+    k: Optional[np.ndarray] = None          # [iterations, chains] draws of a modeled end-node sensitivity k (bart_args k = chi(...)), else None
 
     # ------------------------------------------------------------------ helpers
     def _get(self, name: str, include_warmup, only_warmup):
@@ -210,6 +211,10 @@ class Stan4bartFit:
             return done(self._sigma_arrays(include_warmup, only_warmup))
         if type == "sigma":
             return done(self._get("stan", include_warmup, only_warmup)[self.par_names.index("aux.1")])
+        if type == "k":      # reference R/generics.R:223-224, 280-284
+            if self.k is None:
+                raise ValueError("cannot extract 'k': model was not fit with end-node sensitivity as a modeled parameter")
+            return done(self._get("k", include_warmup, only_warmup))
         if type == "varcount":
             return done(self._get("bart_varcount", include_warmup, only_warmup))
         if type == "stan":
@@ -446,6 +451,7 @@ def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=N
         return dict(stan=_stack(results, phase, "stan"), bart_train=_stack(results, phase, "bart", "train"),
                     bart_test=_stack(results, phase, "bart", "test") if x_bart_test is not None else None,
                     bart_varcount=_stack(results, phase, "bart", "varcount"),
+                    k=_stack(results, phase, "bart", "k") if "k" in results[0][phase]["bart"] else None,     # (R/stan4bart.R:389-399)
                     callback=(np.stack([np.stack(r[phase]["callback"], axis=1) for r in results], axis=2)
                               if callback is not None else None))
     smp = pack("sample")
@@ -463,4 +469,4 @@ def stan4bart(y, x_bart, X=None, groups: Sequence[GroupTerm] = (), x_bart_test=N
         terms=terms, terms_test=terms_test, offset=None if offset is None else np.asarray(offset, dtype=np.float64),
         offset_test=None if offset_test is None else np.asarray(offset_test, dtype=np.float64), offset_type=offset_type,
         range_bart=np.stack([r["range.bart"] for r in results], axis=1), samplers=samplers, callback=smp["callback"],
-        weights=None if kw.get("weights") is None else np.asarray(kw["weights"], dtype=np.float64))
+        weights=None if kw.get("weights") is None else np.asarray(kw["weights"], dtype=np.float64), k=smp["k"])

@@ -97,6 +97,7 @@ class StateView:
             [int(np.frombuffer(self.b, dtype=np.int64, count=1, offset=8)[0])] + np.frombuffer(self.b, dtype=np.int32, count=4, offset=16).tolist()
         assert magic == 0x53423453 and version == 1
         self.n, self.T, self.D, self.binary, self.p = n, T, D, binary, p
+        self.k = float(np.frombuffer(self.b, dtype=np.float64, count=1, offset=32)[0])      # header.reserved[0]: the current value of a modeled k (0.0: k is fixed)
         o = 48
         self.off = {}
         for name, cnt in (("q", D), ("inv_metric", D), ("wm", D), ("wm2", D), ("nuts", 6), ("last", 7)):
@@ -131,6 +132,7 @@ def assert_state_parity(a: "StateView", b: "StateView", rtol=1e-6, atol=1e-9):
     """Two state blobs describe the same chain state: integers / generator states / tree structure bit-exact, floats rtol."""
     for k in ("win", "ecuyer", "r_rng"):
         assert np.array_equal(a.get(k), b.get(k)), k
+    np.testing.assert_allclose(a.k, b.k, rtol=rtol, err_msg="k")
     for k in ("q", "inv_metric", "wm", "wm2", "nuts", "last", "scale", "offset", "total_fits") + (("latents",) if a.binary else ()):
         np.testing.assert_allclose(a.get(k), b.get(k), rtol=rtol, atol=atol, err_msg=k)
     for (na, ma), (nb, mb) in zip(a.trees, b.trees):
@@ -166,6 +168,8 @@ def teacher_forced(oracle_lib, lib, prefix, args, seed=12345, patch=None, compar
             np.testing.assert_allclose(ro["stan"], rp["stan"], rtol=rtol, atol=atol, err_msg=ctx)
             np.testing.assert_allclose(ro["bart"]["train"], rp["bart"]["train"], rtol=rtol, atol=atol, err_msg=ctx)
             assert np.array_equal(ro["bart"]["varcount"], rp["bart"]["varcount"]), ctx
+            if "k" in ro["bart"]:
+                np.testing.assert_allclose(ro["bart"]["k"], rp["bart"]["k"], rtol=rtol, err_msg=ctx + ": k")
             a, b = StateView(so.get_state()), StateView(sp.get_state())
             if compare_states:
                 assert_state_parity(a, b, rtol=rtol, atol=atol)
@@ -241,6 +245,9 @@ def assert_chain_parity(a, b, rtol=1e-6, atol=1e-9, stan=True):
             np.testing.assert_allclose(a[ph]["bart"]["train"], b[ph]["bart"]["train"], rtol=rtol, atol=atol)
             np.testing.assert_allclose(a[ph]["bart"]["test"], b[ph]["bart"]["test"], rtol=rtol, atol=atol)
             np.testing.assert_allclose(a[ph]["bart"]["sigma"], b[ph]["bart"]["sigma"], rtol=rtol)
+            assert ("k" in a[ph]["bart"]) == ("k" in b[ph]["bart"]), "the k draws of a modeled k are missing on one side"
+            if "k" in a[ph]["bart"]:
+                np.testing.assert_allclose(a[ph]["bart"]["k"], b[ph]["bart"]["k"], rtol=rtol, err_msg="k draws")
         if stan and "stan" in a[ph]:
             sa, sb = a[ph]["stan"], b[ph]["stan"]
             # integer-valued sampler columns: treedepth__, n_leapfrog__, divergent__

@@ -204,8 +204,19 @@ class DevCpu {
         apply(t); ++launches_;
       }
       if (binary_) sample_latents();
+      if (kModeled_) draw_k();
     }
   }
+  // ---- k hyperprior (dev_common.hpp k_hyper_*): the same step the HIP layer runs as k_draw_k
+  void set_k_hyper(double df, double scale, double nodeScale, double k0) { kModeled_ = true; kh_.df = df; kh_.invScale2 = std::isinf(scale) ? 0.0 : 1.0 / (scale * scale); kh_.nodeScale = nodeScale; kCur_ = k0; }
+  double k_current() const { return kCur_; }
+  void set_k(double k) { kCur_ = k; a_.model.leafPrec = leaf_precision(k, T_, kh_.nodeScale); }
+  void draw_k() {
+    double sumSq = 0.0, leaves = 0.0;
+    for (int t = 0; t < T_; ++t) { double s, m; k_hyper_tree_stats(a_, t, s, m); sumSq += s; leaves += m; }
+    set_k(k_hyper_draw(&rng_, kh_, T_, sumSq, leaves, kCur_));
+  }
+  bool kModeled_ = false; KHyper kh_{0, 0, 1}; double kCur_ = 2.0;
   // dbarts probit step: z_i ~ N(fit_i + offset_i, 1) truncated by y_i, sequential draws from R's generator
   double lower_trunc_std_normal(double lower) {
     double x;
@@ -245,6 +256,7 @@ class DevCpu {
   void fused_stats(int64_t out[2]) const { out[0] = 0; out[1] = 0; }
   void reset_fused_scales() {}
   void sweep_stats(int64_t out[2]) const { out[0] = 0; out[1] = 0; }
+  int64_t sweep_busy() const { return 0; }
   void profile_sweep(int nSweeps, int thin, double* out) { for (int i = 0; i < 8; ++i) out[i] = 0.0; for (int k = 0; k < nSweeps; ++k) sweep(thin); }
   void test_fits(double* out) {
     for (size_t i = 0; i < nTest_; ++i) {

@@ -131,11 +131,88 @@ def exported_cut_points(lib, prefix, args):
     return out
 
 
-def test_k_hyperprior_is_refused():
-    """bart_args = list(k = chi(1.25, Inf)) (test-09-bartArgs.R:32): dbarts then resamples k every iteration — a sampler step SURVEY.md §8
-    leaves out; the fit refuses it by name instead of silently fixing k."""
-    for k in ("chi(1.25, Inf)", {"chi": (1.25, np.inf)}, None):
-        with pytest.raises(NotImplementedError, match="hyperprior"):
-            friedman_case(n=50, ranef=False, bart_args={"k": k})
+def test_k_prior_forms():
+    """bart_args$k as dbarts takes it (reference R/stan4bart_fit.R:460-465; R/stan4bart.R:202 "allow calls like bart_args = list(k = chi(2, Inf))";
+    tests/testthat/test-09-bartArgs.R:32 uses chi(1.25, Inf)): a number, or the chi(degreesOfFreedom, scale) hyperprior in several spellings."""
+    from stan4bart_amd.fit import _k_prior
+    assert _k_prior(3) == (3.0, None) and _k_prior(2.5) == (2.5, None)
+    for form in ("chi(1.25, Inf)", "chi(degreesOfFreedom = 1.25, scale = Inf)", "chi(1.25)", "chi()", "chi", {"chi": (1.25, np.inf)}, {"chi": {"degreesOfFreedom": 1.25}},
+                 ("chi", 1.25, np.inf), ("chi",)):
+        assert _k_prior(form) == (2.0, (1.25, np.inf)), form
+    assert _k_prior("chi(2, 3.5)") == (2.0, (2.0, 3.5)) and _k_prior({"chi": (4.0, 0.5)}) == (2.0, (4.0, 0.5)) and _k_prior("chi(scale = 2, df = 3)") == (2.0, (3.0, 2.0))
+    for bad in ("gamma(1, 2)", None, {"chi": (0.0, 1.0)}, "chi(1, 0)", "chi(foo = 1)", [1, 2]):
+        with pytest.raises(ValueError):
+            _k_prior(bad)
     args, _ = friedman_case(n=50, ranef=False, bart_args={"k": 3})
-    assert args.k == 3.0
+    assert args.k == 3.0 and args.k_hyper is None
+    args, _ = friedman_case(n=50, ranef=False, bart_args={"k": "chi(1.25, Inf)"})
+    assert args.k == 2.0 and args.k_hyper == (1.25, np.inf)
+
+
+K_CASES = [
+    ("continuous_improper", dict(n=150, ranef=True, slopes=True, bart_args={"k": "chi(1.25, Inf)"}), None),
+    ("continuous_proper_test_rows", dict(n=150, ranef=True, n_test=13, bart_args={"k": {"chi": (3.0, 1.5)}, "n.trees": 9}), None),
+    ("thinned", dict(n=120, ranef=False, skip=(3, 1), bart_args={"k": ("chi", 2.0, 4.0), "n.trees": 6}), None),
+    ("binary", dict(n=180, T=8), "binary"),
+]
+
+
+@pytest.mark.parametrize("name,kw,kind", K_CASES, ids=[c[0] for c in K_CASES])
+def test_k_hyperprior_chain_matches_oracle(oracle_lib, emul_lib, name, kw, kind):
+    """normal(k = chi(df, scale)): after every sweep (trees, then the latents of a binary response) k is drawn from its conditional given the
+    leaf values — one rgamma from R's stream — and the leaf prior precision of the next sweep follows.  Product host logic vs the oracle's
+    independent restatement: tree-move trace and R generator bit-exact, the k draws (the reference's fifth result element "k",
+    src/bart_util.cpp:17-26,75-76) within 1e-6; the draws move and stay in a sane range."""
+    if kind == "binary":
+        from conftest import binary_case
+        args = binary_case(**kw)
+        args.k_hyper, args.k = (1.25, np.inf), 2.0
+    else:
+        args, _ = friedman_case(**kw)
+    a, b = run_chain(oracle_lib, "orc_", args), run_chain(emul_lib, "emu_", args)
+    assert_chain_parity(a, b)
+    kd = np.concatenate([b["warmup"]["bart"]["k"], b["sample"]["bart"]["k"]])
+    assert kd.shape == (args.iter,) and np.all(np.isfinite(kd)) and np.all(kd > 0.05) and np.all(kd < 50) and np.std(kd) > 0
+    # a fixed k returns no fifth element
+    fixed, _ = friedman_case(n=60, ranef=False)
+    assert "k" not in run_chain(emul_lib, "emu_", fixed)["sample"]["bart"]
+
+
+def test_k_hyperprior_bart_block_long_run(oracle_lib, emul_lib):
+    """the BART block alone (results_type 1: no NUTS sensitivity) over 1 500 tree updates with a modeled k"""
+    args, _ = friedman_case(n=300, ranef=False, warmup=50, iter=100, T=15, bart_args={"k": "chi(1.25, Inf)"})
+    a, b = run_chain(oracle_lib, "orc_", args, results_type=1), run_chain(emul_lib, "emu_", args, results_type=1)
+    assert_chain_parity(a, b, stan=False)
+    k = b["sample"]["bart"]["k"]
+    assert 0.3 < np.median(k) < 10
+
+
+def test_k_hyperprior_state_round_trip_and_teacher_forcing(oracle_lib, emul_lib):
+    """the current k is part of the chain state (header.reserved[0] of the blob): teacher forcing through it, and a malformed value is refused"""
+    from conftest import StateView, make_sampler, teacher_forced
+    args, _ = friedman_case(n=120, ranef=True, warmup=8, iter=20, T=7, bart_args={"k": "chi(2, 3)"})
+    teacher_forced(oracle_lib, emul_lib, "emu_", args)
+    s = make_sampler(emul_lib, "emu_", args)
+    try:
+        s.run(3, True)
+        sv = StateView(s.get_state())
+        assert sv.k > 0 and sv.k != 2.0
+        bad = bytearray(sv.bytes()); bad[32:40] = np.float64(-1.0).tobytes()
+        with pytest.raises(RuntimeError, match="k must be positive"):
+            s.set_state(bytes(bad))
+    finally:
+        s.free()
+
+
+def test_r_gamma_is_a_gamma_sampler(oracle_lib):
+    """rgamma from R's stream (nmath/rgamma.c restated twice: oracle/r_rng.hpp, stan4bart_amd/csrc/rrng_hd.hpp): both algorithms (GS for a < 1, GD
+    for a >= 1, every branch of GD's quotient constants) produce the distribution — Kolmogorov-Smirnov against scipy's gamma."""
+    import ctypes as C
+    from scipy import stats
+    if not hasattr(oracle_lib, "orc_test_rgamma"):
+        pytest.skip("oracle built without the rgamma test hook")
+    oracle_lib.orc_test_rgamma.argtypes = [C.c_uint32, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_double)]
+    for shape in (0.3, 0.95, 1.0, 2.2, 3.686, 7.5, 13.022, 40.0, 350.0):
+        out = np.zeros(4000)
+        assert oracle_lib.orc_test_rgamma(77, shape, 1.7, len(out), out.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        assert stats.kstest(out, stats.gamma(shape, scale=1.7).cdf).pvalue > 1e-3, shape

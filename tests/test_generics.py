@@ -311,3 +311,18 @@ def test_concurrent_chains_on_hip(hip_lib):
                                                     for g in groups], type="ev", combine_chains=False)
     np.testing.assert_allclose(p, fit.extract("ev", combine_chains=False)[:9], rtol=1e-9, atol=1e-9)
     fit.close()
+
+
+def test_extract_k_of_a_modeled_end_node_sensitivity(emul_lib):
+    """bart_args = list(k = chi(1.25, Inf)): the fit carries the k draws (reference R/stan4bart.R:389-399) and extract(fit, "k") returns
+    them, chain 1 first; without a hyperprior extract("k") is the reference's error (R/generics.R:223-224)."""
+    d, xb, X, groups, rows, groups_t = _data()
+    kw = dict(X=X, groups=groups, chains=2, seed=4, iter=12, warmup=5, make_sampler=lambda a, st: Sampler(emul_lib, "emu_", a, st))
+    fit = stan4bart(d["y"], xb, bart_args={"n.trees": 6, "k": "chi(1.25, Inf)"}, **kw)
+    k = fit.extract("k", combine_chains=False)
+    assert k.shape == (7, 2) and np.all(k > 0) and np.std(k) > 0
+    np.testing.assert_array_equal(fit.extract("k"), np.concatenate([k[:, 0], k[:, 1]]))
+    assert fit.extract("k", include_warmup=True, combine_chains=False).shape == (12, 2) and fit.extract("k", include_warmup="only", combine_chains=False).shape == (5, 2)
+    plain = stan4bart(d["y"], xb, bart_args={"n.trees": 6}, **kw)
+    with pytest.raises(ValueError, match="end-node sensitivity"):
+        plain.extract("k")

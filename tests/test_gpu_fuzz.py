@@ -63,6 +63,9 @@ def random_case(seed):
     big_trees = bool(g2.random() < 0.25) and 400 <= n <= 4000      # trees drawn from a very deep prior: more than 64 node slots from the first sweep on
     if big_trees:
         bart_args.update(base=0.99, power=0.25, k=0.3)
+    g3 = np.random.default_rng(99000 + seed)       # (round 5: a modeled k — its own stream again)
+    if g3.random() < 0.2 and not big_trees:
+        bart_args["k"] = ("chi", float(g3.choice([1.25, 2.0, 6.0])), float(g3.choice([np.inf, np.inf, 1.5])))
     warmup = int(g.integers(2, 12))
     it = warmup + int(g.integers(4, 40 if deep else 25))
     n_test = int(g.integers(0, 3)) * int(g.integers(1, min(n, 20)))

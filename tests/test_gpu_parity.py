@@ -462,3 +462,34 @@ def test_hand_over_from_the_one_workgroup_sweep(oracle_lib, hip_lib):
     b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path="persistent")
     assert b["tree_path"][1] == "persistent" and b["sweep_stats"][1] >= 10
     assert_chain_parity(a, b, stan=False)
+
+
+@pytest.mark.parametrize("path", ["persistent", "fused", "two-kernel"])
+@pytest.mark.parametrize("kind", ["continuous", "binary"])
+def test_k_hyperprior_on_every_tree_path(oracle_lib, hip_lib, kind, path):
+    """normal(k = chi(1.25, Inf)) (reference R/stan4bart.R:202, tests/testthat/test-09-bartArgs.R:32): after every sweep — trees, then the
+    latents of a binary response — k_draw_k draws k from its conditional given the leaf values, from R's stream on the device, and the leaf
+    prior precision of the next sweep's launches follows.  BART block over 1 500 tree updates on each tree path, against the oracle's
+    independent restatement: trace and generator bit-exact, k draws (result element "k", src/bart_util.cpp:17-26,75-76) within 1e-6."""
+    if kind == "binary":
+        from conftest import binary_case
+        args = binary_case(n=3000, T=15, warmup=40, iter=100)
+        args.k_hyper, args.k = (1.25, np.inf), 2.0
+    else:
+        args, _ = friedman_case(n=3000, T=15, warmup=40, iter=100, bart_args={"k": "chi(1.25, Inf)"})
+    a = run_chain(oracle_lib, "orc_", args, results_type=1)
+    b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path=path)
+    assert b["tree_path"][1] == path
+    assert_chain_parity(a, b, stan=False)
+    k = b["sample"]["bart"]["k"]
+    assert k.shape == (60,) and np.std(k) > 0 and 0.2 < np.median(k) < 20
+
+
+def test_k_hyperprior_joint_chain_and_teacher_forcing(oracle_lib, hip_lib):
+    """the joint chain with a modeled k over the reference's test horizon, and teacher-forced through the state blob (the current k travels
+    in header.reserved[0])"""
+    from conftest import teacher_forced
+    args, _ = friedman_case(n=500, ranef=True, slopes=True, n_test=11, bart_args={"k": "chi(2.5, 4)"})
+    assert_chain_parity(run_chain(oracle_lib, "orc_", args), run_chain(hip_lib, "s4b_", args))
+    args, _ = friedman_case(n=400, ranef=True, warmup=10, iter=30, T=9, bart_args={"k": "chi(1.25, Inf)"})
+    teacher_forced(oracle_lib, hip_lib, "s4b_", args)

@@ -1,0 +1,45 @@
+"""Guard of k_sweep's register allocation (compile only: hipcc cross-compiles gfx950 without a GPU).
+
+The persistent sweep kernel sits exactly at its 256-VGPR budget (two waves per SIMD: eight role waves per workgroup, one workgroup per CU).
+DESIGN.md 8 (round 4) measured that an unrelated source change moved its spill count from 21-24 to 13 VGPRs and the benchmark by 6 %: what
+the phases of a step cost is as much a question of what the allocator keeps in registers across the role loops as of the algorithm.  This
+test makes such a change visible in `pytest -m "not gpu"` instead of on the next benchmark: it compiles the kernel's translation unit for
+the device only, with the product's flags (the Makefile's own SWEEPFLAGS), and reads `-Rpass-analysis=kernel-resource-usage`."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "stan4bart_amd", "csrc")
+MAX_SPILLED_VGPRS = 16       # product build of round 5: 13
+MAX_SCRATCH_BYTES = 1960     # product build of round 5: 1896 bytes per lane (the hand-over tail's global-memory control step, not the step loops)
+
+
+def _usage(extra=()):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not found")
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    cxx = re.search(r"^CXXFLAGS \?= (.*)$", mk, re.M).group(1).split()
+    swp = re.search(r"^SWEEPFLAGS \?= (.*)$", mk, re.M).group(1).split()
+    cmd = [hipcc, "--offload-arch=gfx950", *cxx, *swp, *extra, "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-c", "-o", os.devnull, "dev_sweep.hip"]
+    out = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:]
+    blocks = re.split(r"remark: Function Name: ", out.stdout)[1:]
+    sweep = [b for b in blocks if "k_sweep" in b.split()[0]]
+    assert len(sweep) == 1, [b.split()[0] for b in blocks]
+
+    def field(name):
+        return int(re.search(name + r": (\d+)", sweep[0]).group(1))
+    return dict(vgprs=field("VGPRs"), spill=field("VGPRs Spill"), scratch=field(r"ScratchSize \[bytes/lane\]"), occupancy=field(r"Occupancy \[waves/SIMD\]"),
+                lds=field(r"LDS Size \[bytes/block\]"))
+
+
+def test_k_sweep_register_allocation_is_the_one_that_was_measured():
+    u = _usage()
+    assert u["vgprs"] <= 256 and u["occupancy"] >= 2, u          # eight waves of one workgroup must fit a CU
+    assert u["spill"] <= MAX_SPILLED_VGPRS, f"k_sweep now spills {u['spill']} VGPRs (measured build: 13; 21-24 cost 6 % of the benchmark): {u}"
+    assert u["scratch"] <= MAX_SCRATCH_BYTES, f"k_sweep's scratch grew to {u['scratch']} bytes per lane (measured build: 1896): {u}"

@@ -18,7 +18,7 @@ def _load():
         return json.load(f)
 
 
-SCENARIOS = ("c1", "binary", "split_probs", "quantiles")      # "c1" = the file's top level; the others under "scenarios" (tools/make_goldens.R)
+SCENARIOS = ("c1", "binary", "split_probs", "quantiles", "k_hyperprior")      # "c1" = the file's top level; the others under "scenarios" (tools/make_goldens.R)
 
 
 def _chain(lib, prefix, scenario="c1"):
@@ -31,6 +31,8 @@ def _chain(lib, prefix, scenario="c1"):
         bart_args.update({"split.probs": {"X3": 2, ".default": 1}, "predictor.names": ["X1", "X2", "X3", "X5", "X6", "X7", "X8", "X9", "X10"]})
     if scenario == "quantiles":
         bart_args.update({"useQuantiles": True, "n.cuts": 20})
+    if scenario == "k_hyperprior":
+        bart_args.update({"k": "chi(1.25, Inf)"})
     args = make_sampler_args(d["y"], x[:, [0, 1, 2, 4, 5, 6, 7, 8, 9]], X=np.column_stack([x[:, 3], d["z"]]),
                              groups=[GroupTerm(d["g1"], x[:, 3] if scenario == "c1" else None, "g.1"), GroupTerm(d["g2"], None, "g.2")],
                              family="binomial" if binary else "gaussian", iter=13, warmup=7, bart_args=bart_args)
@@ -48,6 +50,8 @@ def _compare(g, d, out):
     train = np.asarray(g["bart_train"]).reshape(g["bart_train_dim"], order="F")
     np.testing.assert_array_equal(np.asarray(g["varcount"]).reshape(9, -1, order="F"), out["sample"]["bart"]["varcount"])   # tree moves: exact
     np.testing.assert_allclose(out["sample"]["bart"]["train"], train, rtol=1e-6, atol=1e-9)
+    if len(g.get("k", [])):                              # (a modeled k: the reference's fifth bart result)
+        np.testing.assert_allclose(out["sample"]["bart"]["k"], g["k"], rtol=1e-6)
     if len(g["sigma"]):                                  # (a probit fit has no sigma)
         np.testing.assert_allclose(out["sample"]["bart"]["sigma"], g["sigma"], rtol=1e-6)
     stan = np.asarray(g["stan"]).reshape(g["stan_dim"], order="F")

@@ -148,7 +148,12 @@ def r_arguments(R, a, callback=None, drop=None):
     data = R.s4({"x": R.real(xb, dim=(n, p)), "n.cuts": R.integer(np.broadcast_to(np.asarray(a.n_cuts), (p,))),
                  "x.test": R.real(a.x_test, dim=np.asarray(a.x_test).shape) if a.x_test is not None and len(a.x_test) else R.nil()})
     pp = a.proposal_probs
-    model = R.s4({"tree.prior": R.s4({"power": R.real([a.power]), "base": R.real([a.base])}), "node.prior": R.s4({"k": R.real([a.k])}), "node.scale": R.real([ns]),
+    # normal(k): node.prior carries k and node.hyperprior is dbarts' fixed hyperprior; normal(k = chi(df, scale)): node.hyperprior is a
+    # dbartsChiHyperprior with the slots degreesOfFreedom and scale (R/stan4bart_fit.R:460-479)
+    k_hyper = getattr(a, "k_hyper", None)
+    hyper = R.s4({"k": R.real([a.k])}) if k_hyper is None else R.s4({"degreesOfFreedom": R.real([k_hyper[0]]), "scale": R.real([k_hyper[1]])})
+    model = R.s4({"tree.prior": R.s4({"power": R.real([a.power]), "base": R.real([a.base])}), "node.prior": R.s4({"k": R.real([a.k])}) if k_hyper is None else R.s4({}),
+                  "node.hyperprior": hyper, "node.scale": R.real([ns]),
                   "p.birth_death": R.real([pp[0]]), "p.swap": R.real([pp[1]]), "p.change": R.real([pp[2]]), "p.birth": R.real([pp[3]])})
     X = np.asarray(a.X if a.X is not None else np.zeros((n, 0)), dtype=np.float64).reshape(n, -1)
     K = X.shape[1]
@@ -244,7 +249,9 @@ def drive(R, clib, prefix, n=150, n_test=9):
     stan_s = R.to_numpy(rs["stan"])
     assert R.strings(R.lib.mock_elt(R.lib.mock_get_attr(rs["stan"], b"dimnames"), 0)) == par_names
     bart_s = R.as_dict(rs["bart"])
-    assert list(bart_s) == ["sigma", "train", "test", "varcount"]
+    import json
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_call_interface.json")))
+    assert list(bart_s) == ref["bartResultNames"] == ["sigma", "train", "test", "varcount"]
     assert np.array_equal(R.to_numpy(rw["stan"]), w["stan"]) and np.array_equal(stan_s, r["stan"])
     assert np.array_equal(R.to_numpy(bart_s["train"]), r["bart"]["train"]) and np.array_equal(R.to_numpy(bart_s["test"]), r["bart"]["test"])
     assert np.array_equal(R.to_numpy(bart_s["sigma"]), r["bart"]["sigma"]) and np.array_equal(R.to_numpy(bart_s["varcount"]), r["bart"]["varcount"])
@@ -321,6 +328,45 @@ def test_shim_argument_errors_are_r_errors(shim_emul):
     out = R.call("stan4bart_run", ptr, R.integer([3]), R.lgl(True), R.string("both"))
     assert R.names(out) == ["callback"] and R.type(R.lib.mock_elt(out, 0)) == NILSXP
     R.call("stan4bart_finalize")
+
+
+def _k_through_the_shim(R, clib, prefix, n=140):
+    """bart_args = list(k = chi(1.25, Inf)) through the .Call layer: model@node.hyperprior is unpacked, the bart result list has the
+    reference's fifth element "k" (src/bart_util.cpp:17-26,60-64,75-76) and equals the ctypes path's draws bit for bit."""
+    from stan4bart_amd import RRng
+    from stan4bart_amd.abi import Sampler
+    args, _ = friedman_case(n=n, T=6, warmup=4, iter=9, bart_args={"k": "chi(1.25, Inf)"})
+    rng = RRng(99)
+    args.seed = int(rng.sample_int(2147483647, 1)[0])
+    state0 = rng.state.copy()
+    s = Sampler(clib, prefix, args, state0)
+    w = s.run(args.warmup, True, 0)
+    s.disengage_adaptation()
+    r = s.run(args.iter - args.warmup, False, 0)
+    s.free()
+    R.set_seed(state0)
+    ptr = R.call("stan4bart_create", *r_arguments(R, args))
+    rw = R.as_dict(R.as_dict(R.call("stan4bart_run", ptr, R.integer([args.warmup]), R.lgl(True), R.string("both")))["bart"])
+    R.call("stan4bart_disengageAdaptation", ptr)
+    rs = R.as_dict(R.as_dict(R.call("stan4bart_run", ptr, R.integer([args.iter - args.warmup]), R.lgl(False), R.string("both")))["bart"])
+    import json
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_call_interface.json")))
+    assert list(rs) == ref["bartResultNamesWithModeledK"] == ["sigma", "train", "test", "varcount", "k"]
+    assert np.array_equal(R.to_numpy(rw["k"]), w["bart"]["k"]) and np.array_equal(R.to_numpy(rs["k"]), r["bart"]["k"])
+    assert np.array_equal(R.to_numpy(rs["train"]), r["bart"]["train"]) and np.std(r["bart"]["k"]) > 0
+    R.call("stan4bart_finalize")
+    return True
+
+
+def test_shim_returns_the_k_draws_of_a_modeled_k(shim_emul):
+    assert _k_through_the_shim(shim_emul, shim_emul.lib, "s4b_")
+
+
+@pytest.mark.gpu
+def test_shim_returns_the_k_draws_over_the_hip_library(hip_lib):
+    _build()
+    R = MockR(os.path.join(MOCK_DIR, "_build", "libshim_hip.so"))
+    assert _k_through_the_shim(R, hip_lib, "s4b_", n=1500)
 
 
 @pytest.mark.gpu

@@ -8,7 +8,8 @@
 #   y ~ bart(. - g.1 - g.2 - X4 - z) + X4 + z + (1 + X4 | g.1) + (1 | g.2),
 # seed = 12345, chains = 1, cores = 1, warmup = 7, iter = 13, bart_args = list(n.trees = 11, keepTrees = TRUE).
 # Further scenarios under "scenarios" (same seed and lengths, (1 | g.1) + (1 | g.2)): a binary response (probit link,
-# tests/testthat/test-02-binary.R), cgm(split.probs = c(X3 = 2, .default = 1)) (test-09-bartArgs.R:20), useQuantiles = TRUE.
+# tests/testthat/test-02-binary.R), cgm(split.probs = c(X3 = 2, .default = 1)) (test-09-bartArgs.R:20), useQuantiles = TRUE,
+# k = chi(1.25, Inf) (a modeled k).
 # The file records the versions of R, stan4bart and dbarts that made it.
 # tests/test_reference_goldens.py compares the oracle (and, on a GPU box, the HIP path) with the file when it exists:
 # data (generator parity), per-draw sigma / BART fits / variable counts / Stan rows, and the kept trees, for every scenario.
@@ -33,6 +34,7 @@ scenario <- function(testData, formula, bart_args, ...) {
     sigma       = if (is.null(fit$sigma)) numeric(0) else num(extract(fit, "sigma")),
     bart_train  = num(fit$bart_train[,,1L]), bart_train_dim = dim(fit$bart_train)[1L:2L],
     varcount    = as.integer(fit$bart_varcount[,,1L]),
+    k           = if (is.null(fit$k)) numeric(0) else num(fit$k[,1L]),
     range_bart  = num(fit$range.bart[,1L]),
     trees       = list(sample = as.integer(trees$sample), tree = as.integer(trees$tree), n = as.integer(trees$n),
                        var = as.integer(trees$var), value = num(trees$value))
@@ -54,7 +56,9 @@ golden$scenarios <- list(
   # weighted predictor choice (test-09-bartArgs.R:20)
   split_probs = scenario(continuous, plain, list(n.trees = 11, keepTrees = TRUE, split.probs = c(X3 = 2, .default = 1))),
   # cut points at quantiles
-  quantiles   = scenario(continuous, plain, list(n.trees = 11, keepTrees = TRUE, useQuantiles = TRUE, n.cuts = 20L))
+  quantiles   = scenario(continuous, plain, list(n.trees = 11, keepTrees = TRUE, useQuantiles = TRUE, n.cuts = 20L)),
+  # end-node sensitivity as a modeled parameter (R/stan4bart.R:202; dbarts' chi hyperprior): the per-sweep draw of k and where it sits in R's stream
+  k_hyperprior = scenario(continuous, plain, list(n.trees = 11, keepTrees = TRUE, k = quote(chi(1.25, Inf))))
 )
 
 to_json <- function(x, digits = 17L) {

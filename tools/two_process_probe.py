@@ -21,6 +21,7 @@ t0 = time.time()
 try:
     for it in range(40):
         s.run(100, True, 1)
-    print(tag, "finished 4000 iterations in", round(time.time() - t0, 2), "s; sweeps (run, handed over)", s.get_sweep_stats(), flush=True)
+    print(tag, "finished 4000 iterations in", round(time.time() - t0, 2), "s; sweeps (run, handed over)", s.get_sweep_stats(),
+          "persistent launches that found the device shared (their sweeps ran as k_step launches):", s.get_sweep_busy(), flush=True)
 except RuntimeError as e:
     print(tag, "stopped after", round(time.time() - t0, 2), "s with:", str(e)[:300], flush=True)
