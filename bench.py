@@ -49,7 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
-DOMINANT = {"fused": "k_step", "two-kernel": "k_tree", "persistent": "k_sweep"}
+DOMINANT = {"fused": "k_step", "two-kernel": "k_tree", "persistent": "k_sweep", "stream": "k_sweep_stream"}
 
 
 def source_sha16():
@@ -116,7 +116,7 @@ def sweep_roofline(prof, path, n, trees):
     """Roofline record of the dominant kernel of one sweep.  Algorithmic bytes of a tree update: R read 8 + R write 8 + leaf id of
     the finished tree 2 + leaf id of the tree whose statistics are gathered 2 + binned predictor 2 = 22 B per observation."""
     # (the persistent path runs a whole sweep — `trees` tree updates — in ONE launch of k_sweep: its launch does `trees` times the work)
-    per_launch = 22.0 * n * (trees if path == "persistent" else 1)
+    per_launch = 22.0 * n * (trees if path in ("persistent", "stream") else 1)
     rec = {"bound": "hbm", "kernel": DOMINANT[path], "tree_path": path, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "avg_launch_us": prof["stats_us"], "algorithmic_bytes_per_launch": per_launch,
            "timing": "HIP events around every launch on the sampler's stream (adds ~2 us per launch; profiles/ has rocprofv3)",
@@ -124,13 +124,16 @@ def sweep_roofline(prof, path, n, trees):
            "achieved_GBs_whole_sweep": 22.0 * n * trees / (prof["sweep_wall_us"] * 1e-6) / 1e9}
     rec["achieved"] = per_launch / (prof["stats_us"] * 1e-6) / 1e9
     rec["frac"] = rec["achieved"] / HBM_PEAK_GBS
-    if path == "persistent":
+    if path in ("persistent", "stream"):
         rec["tree_updates_per_launch"] = trees
         rec["avg_tree_update_us"] = prof["stats_us"] / trees
         rec["sweeps_handed_over_to_k_step"] = prof["control_us"]     # a tree outgrew the 64 node slots of the wave-register control path
         rec["persistent_sweeps"] = prof["launches"][1]
         rec["note"] = ("algorithmic bytes (SURVEY 8d: 22 B per observation and tree update) / launch duration; the launch itself moves far less: "
-                       "the residual stays in registers for the whole sweep (per tree update 2 B leaf id + 2-6 B predictor columns read, 2 B written under an accepted move)")
+                       "the residual stays in registers for the whole sweep (per tree update 2 B leaf id + 2-6 B predictor columns read, 2 B written under an accepted move)"
+                       if path == "persistent" else
+                       "one launch per sweep; the pass waves stream residual (read + write), both leaf planes and the predictor column of the pending rules per tree: "
+                       "the 22 algorithmic bytes per observation and tree update really move")
         return rec
     if path == "two-kernel":
         rec["separate_control_kernel_us"] = prof["control_us"]
@@ -291,7 +294,7 @@ def main():
     ap.add_argument("--no-hmc-mode1", action="store_true")
     ap.add_argument("--mode-iters", type=int, default=100, help="iterations of the like-for-like leg that times both gradient modes from one saved state")
     ap.add_argument("--profile-sweeps", type=int, default=2)
-    ap.add_argument("--tree-path", default="auto", choices=["auto", "two-kernel", "fused", "persistent"])
+    ap.add_argument("--tree-path", default="auto", choices=["auto", "two-kernel", "fused", "persistent", "stream"])
     ap.add_argument("--c5-n", type=int, default=10_000_000, help="observations of the BASELINE config 5 leg of extra_configs (0 = skip; N = 1 only)")
     ap.add_argument("--target-n", type=int, default=10_000_000,
                     help="also measure the sweep kernel at north_star's roofline-target size (0 = skip; N = 1 only)")

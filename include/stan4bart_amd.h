@@ -285,13 +285,15 @@ int S4B_FN(get_leaf_assignment)(s4b_sampler* s, int32_t tree, int32_t* out);
  * per-bin sums (1e-15 relative).  May be called at any time between runs. */
 int S4B_FN(set_device_sharing)(s4b_sampler* s, int32_t chains);
 /* Not a reference routine.  Which device code runs a tree update: 0 automatic (default), 1 two kernels per tree (k_tree + k_control),
- * 2 one fused launch per tree (k_step), 4 persistent (k_sweep: ONE launch per
- * sweep, the residual in registers, bin partials exchanged through order-free integer atomics; the automatic choice wherever it
- * applies: no weights, at most 16 observations per pass thread (n <= 1.3e6), the chain has the device to itself).  A request the
- * sampler cannot honour (more than 255 quads per thread for 2, the conditions above for 4) falls back to the next path down; get_tree_path reports the path in effect.  The same chain on every
- * path (see set_device_sharing).  May be called at any time between runs.
- * get_tree_path: out[0] = the request, out[1] = the path in effect (1, 2 or 4).  (3 was the lagged launch of
- * an earlier revision: removed, the value is rejected.) */
+ * 2 one fused launch per tree (k_step), 4 persistent (k_sweep: ONE launch per sweep, the residual in the registers of the pass waves, bin
+ * partials exchanged through order-free integer atomics), 5 persistent with a streaming pass (k_sweep_stream: the same launch, the pass
+ * waves read and write the residual per tree; measured slower than 1 / 2 at every size and never chosen automatically).  The automatic
+ * choice is 4 wherever it applies — no observation weights, no cgm(split.probs), the chain has the device to itself, at most 16
+ * observations per pass thread (n <= 1 044 480 on 256 compute units) —, else 2 up to n ~ 4e6, else 1.  A request the sampler cannot honour
+ * (more than 255 quads per thread for 2, the conditions above for 4 / 5) falls back to the next path down; get_tree_path reports the path
+ * in effect.  The same chain on every path (see set_device_sharing).  May be called at any time between runs.
+ * get_tree_path: out[0] = the request, out[1] = the path in effect (1, 2, 4 or 5).  (3 was the lagged launch of an earlier revision:
+ * removed, the value is rejected.) */
 int S4B_FN(set_tree_path)(s4b_sampler* s, int32_t path);
 int S4B_FN(get_tree_path)(s4b_sampler* s, int32_t out[2]);
 /* counters: {log-density gradient evaluations, tree updates, device kernel launches} */

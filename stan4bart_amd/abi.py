@@ -448,11 +448,12 @@ class Sampler:
         if fn is not None:          # (the CPU oracle has no such notion)
             self._check(fn(self._h, int(chains)))
 
-    TREE_PATHS = {"auto": 0, "two-kernel": 1, "fused": 2, "persistent": 4}
+    TREE_PATHS = {"auto": 0, "two-kernel": 1, "fused": 2, "persistent": 4, "stream": 5}
 
     def set_tree_path(self, path):
-        """Device code of a tree update: "auto", "two-kernel" (k_tree + k_control), "fused" (k_step) or "persistent" (k_sweep: one
-        launch per sweep)."""
+        """Device code of a tree update: "auto", "two-kernel" (k_tree + k_control), "fused" (k_step), "persistent" (k_sweep: one
+        launch per sweep, the residual in registers) or "stream" (k_sweep_stream: the same launch with a streaming pass; on request
+        only — it is slower than the other paths at every size)."""
         fn = getattr(self._lib, self._pfx + "set_tree_path", None)
         if fn is not None:          # (the CPU oracle has one path)
             self._check(fn(self._h, int(self.TREE_PATHS.get(path, path))))

@@ -2061,12 +2061,17 @@ class DevHip {
       // each other inside the launch) and no weights.
       {
         hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, device_));
-        sweepOk_ = fusedOk_ && d.weights == nullptr && nQuads <= (int64_t)(a.gridF - 1) * SW_PT * SW_PF && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount &&
-                   sweep_lds_bytes() + 40 * 1024 <= 160 * 1024;
+        // beyond SW_PF quads per pass thread the residual does not fit the registers.  The STREAMING variant of the same launch (k_sweep_stream:
+        // the pass waves read and write the residual per tree, 22 B per observation and tree update like k_tree, everything else as k_sweep)
+        // exists for every size but is only taken on request (choose_path); its workgroup counts must fit the 21-bit field of the exchange words
+        const bool common = fusedOk_ && d.weights == nullptr && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount && sweep_lds_bytes() + 40 * 1024 <= 160 * 1024;
+        sweepRegsOk_ = common && nQuads <= (int64_t)(a.gridF - 1) * SW_PT * SW_PF;
+        sweepStreamOk_ = common && (n_ + a.gridF - 2) / (a.gridF - 1) + 4 * SW_PT < (int64_t)1 << 21;
+        sweepOk_ = sweepRegsOk_ || sweepStreamOk_;
         // at most 4096 observations: ONE workgroup holds them all and does the control duties too (no exchange: dev_sweep.inc "solo")
-        sweepGrid_ = nQuads <= (int64_t)SW_PT * SW_PF ? 1 : a.gridF;
+        sweepSolo_ = nQuads <= (int64_t)SW_PT * SW_PF;
 #ifdef S4B_TUNING
-        if (getenv("S4B_NOSOLO")) sweepGrid_ = a.gridF;
+        if (getenv("S4B_NOSOLO")) sweepSolo_ = false;
 #endif
         if (sweepOk_) {
           xbuf_ = zalloc<unsigned long long>((size_t)2 * (XC_RING * XC_BUF_WORDS + XC_ROLL_WORDS));   // two rings (+ the words of the roll call behind each): a launch uses one and clears the other for the next launch
@@ -2074,6 +2079,7 @@ class DevHip {
           sweepStatus_[0] = -1;
           { void* dp = nullptr; HIP_OK(hipHostGetDevicePointer(&dp, sweepStatus_, 0)); sweepStatusDev_ = (int32_t*)dp; }
           HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
+          HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
         }
       }
       choose_path();
@@ -2311,10 +2317,16 @@ class DevHip {
     sweepLock_ = std::unique_lock<std::mutex>(sweep_mutex(device_));
     for (int i = 0; i < 16; ++i) sweepStatus_[i] = 0;
     sweepStatus_[0] = -1;
-    hipLaunchKernelGGL(k_sweep, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
+    launch_sweep_kernel();
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sweepLock_.unlock(); HIP_OK(e); }
   }
+  void launch_sweep_kernel() {
+    if (sweepStream_) hipLaunchKernelGGL(k_sweep_stream, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
+    else hipLaunchKernelGGL(k_sweep, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
+    ++launches_;
+  }
+  bool sweep_streams() const { return sweepStream_; }
   SweepArgs sweep_args() {     // (the exchange ring of this launch, the one it clears for the next launch)
     unsigned long long* cur = xbuf_ + (size_t)xbufParity_ * (XC_RING * XC_BUF_WORDS + XC_ROLL_WORDS);
     unsigned long long* nxt = xbuf_ + (size_t)(1 - xbufParity_) * (XC_RING * XC_BUF_WORDS + XC_ROLL_WORDS);
@@ -2364,7 +2376,7 @@ class DevHip {
   // finished with k_step launches and the Stan inputs are formed again — they only read the BART state and overwrite their own outputs;
   // what the discarded first evaluation did to the host-side state of the fixed-point sums (scales, counters) is put back first.
   void sweep_and_stan_inputs(int thin, int mode, bool wantTrain, double* cX, double* cZ, double* s0, double* trainOut) {
-    if (path_ != PATH_SWEEP || binary_ || thin < 1 || !persistent_now() || kModeled_) { sweep(thin); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); return; }
+    if (!is_persistent() || binary_ || thin < 1 || !persistent_now() || kModeled_) { sweep(thin); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); return; }
     for (int k = 0; k + 1 < thin; ++k) sweep_persistent_one();
     if (!persistent_now()) { ++sweepCount_; sweep_fused_one(); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); return; }
     TurnGuard turn(*this);
@@ -2380,13 +2392,13 @@ class DevHip {
     flush_hand_off();
     if (kModeled_) {      // one sweep at a time: trees, latents, k — then the host knows the precision the next sweep's launches carry
       for (int k = 0; k < thin; ++k) {
-        if (path_ == PATH_SWEEP) sweep_persistent_one(); else sweep_eager(1, false);
+        if (is_persistent()) sweep_persistent_one(); else sweep_eager(1, false);
         if (binary_) launch_latents();
         draw_k();
       }
       return;
     }
-    if (path_ == PATH_SWEEP) {
+    if (is_persistent()) {
       for (int k = 0; k < thin; ++k) { sweep_persistent_one(); if (binary_) launch_latents(); }
       return;
     }
@@ -2552,23 +2564,31 @@ class DevHip {
     out[6] = ms * 1000.0 / nSweeps;
   }
   bool fused() const { return useFused_; }
-  // tree-update path: 0 automatic, 1 two kernels per tree (k_tree + k_control), 2 fused (k_step), 4 persistent (k_sweep); 3 was the
-  // lagged launch (k_lag) of round 3, removed: the persistent sweep does what it was after without its repair launches
+  // tree-update path: 0 automatic, 1 two kernels per tree (k_tree + k_control), 2 fused (k_step), 4 persistent (k_sweep: residual in the
+  // registers of the pass waves), 5 persistent with the streaming pass (k_sweep_stream: on request only, at any size); 3 was the lagged
+  // launch (k_lag) of round 3, removed
   void set_tree_path(int path) {
-    if (path < 0 || path > 4 || path == 3) throw std::invalid_argument("tree path must be 0 (automatic), 1 (two-kernel), 2 (fused) or 4 (persistent)");
+    if (path < 0 || path > 5 || path == 3) throw std::invalid_argument("tree path must be 0 (automatic), 1 (two-kernel), 2 (fused), 4 (persistent) or 5 (persistent, streaming pass)");
     pathReq_ = path; choose_path();
   }
   void get_tree_path(int32_t out[2]) const { out[0] = pathReq_; out[1] = path_; }
+  bool is_persistent() const { return path_ == PATH_SWEEP || path_ == PATH_STREAM; }
   void choose_path() {
     int want = pathReq_;
     // automatic: the fused launch while a tree update is latency-bound (few quads per thread), two kernels per tree beyond and when
     // three or more chains share the device.
     // The persistent sweep wherever it applies and the chain has the device to itself (its workgroups wait for each other).
-    if (want == 0) want = sharing_ >= 3 ? PATH_TWO : ((sweepOk_ && sharing_ <= 1) ? PATH_SWEEP : (fusedAuto_ ? PATH_FUSED : PATH_TWO));
-    if (want == PATH_SWEEP && !sweepOk_) want = fusedOk_ ? PATH_FUSED : PATH_TWO;
+    // (The streaming variant of the persistent launch is never the automatic choice: from the four register-heavy pass waves of a compute
+    // unit it streams at 3.1 TB/s — 70.8 us per tree update at n = 1e7 against 62.7 for k_tree + k_control, 24.0 against 24.1 for k_step at
+    // n = 2e6: DESIGN.md 8, round 5.)
+    if (want == 0) want = sharing_ >= 3 ? PATH_TWO : ((sweepRegsOk_ && sharing_ <= 1) ? PATH_SWEEP : (fusedAuto_ ? PATH_FUSED : PATH_TWO));
+    if (want == PATH_SWEEP && !sweepRegsOk_) want = fusedOk_ ? PATH_FUSED : PATH_TWO;
+    if (want == PATH_STREAM && !sweepStreamOk_) want = fusedOk_ ? PATH_FUSED : PATH_TWO;
     if (want == PATH_FUSED && !fusedOk_) want = PATH_TWO;
     if (want == path_) return;
     path_ = want; useFused_ = path_ == PATH_FUSED;
+    sweepStream_ = path_ == PATH_STREAM;
+    sweepGrid_ = (path_ == PATH_SWEEP && sweepSolo_) ? 1 : a_.gridF;
     if (graphExec_) { (void)hipGraphExecDestroy(graphExec_); graphExec_ = nullptr; }
   }
   // Hint: `chains` samplers share this device.  The fused launch keeps every CU busy with one workgroup of 8 register-heavy waves,
@@ -2589,7 +2609,7 @@ class DevHip {
         std::lock_guard<std::mutex> turn(sweep_mutex(device_));
         HIP_OK(hipEventRecord(evStart_, stream_));
         sweepStatus_[0] = -1;
-        hipLaunchKernelGGL(k_sweep, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args()); ++launches_;
+        launch_sweep_kernel();
         HIP_OK(hipEventRecord(evStop_, stream_));
         sync();
       }
@@ -2643,7 +2663,7 @@ class DevHip {
     out[6] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / nSweeps;
   }
   void profile_sweep(int nSweeps, int thin, double* out) {
-    if (path_ == PATH_SWEEP) { profile_sweep_persistent(nSweeps, thin, out); return; }
+    if (is_persistent()) { profile_sweep_persistent(nSweeps, thin, out); return; }
     if (useFused_) { profile_sweep_fused(nSweeps, thin, out); return; }
     const int perSweep = 2 * T_ * thin + thin;
     std::vector<hipEvent_t> ev((size_t)perSweep * 2 + 4);
@@ -2951,8 +2971,8 @@ class DevHip {
   int device_ = 0; hipStream_t stream_ = nullptr; hipEvent_t evStart_ = nullptr, evStop_ = nullptr;
   int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1; bool binary_ = false;
   size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0; bool useFused_ = false, fusedAuto_ = false, fusedOk_ = false;
-  enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_SWEEP = 4 };
-  bool sweepOk_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
+  enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_SWEEP = 4, PATH_STREAM = 5 };
+  bool sweepOk_ = false, sweepRegsOk_ = false, sweepStreamOk_ = false, sweepSolo_ = false, sweepStream_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
   int64_t sweepCount_ = 0, sweepHandOvers_ = 0;
   int xbufParity_ = 0; long long dbgSweepNo_ = 0; int sweepGrid_ = 0;
   OffsetArgs pend_; bool pendOffset_ = false, pendSigma_ = false;   // Stan -> BART hand-off calls held for the one-launch form (offset_from_params)

@@ -251,7 +251,7 @@ class DevCpu {
   }
   void profile_leapfrog(int, const double*, const double*, double* out) { out[0] = out[1] = out[2] = 0.0; }
   void set_device_sharing(int) {}
-  void set_tree_path(int path) { if (path < 0 || path > 4 || path == 3) throw std::invalid_argument("tree path must be 0 (automatic), 1 (two-kernel), 2 (fused) or 4 (persistent)"); pathReq_ = path; }
+  void set_tree_path(int path) { if (path < 0 || path > 5 || path == 3) throw std::invalid_argument("tree path must be 0 (automatic), 1 (two-kernel), 2 (fused), 4 (persistent) or 5 (persistent, streaming pass)"); pathReq_ = path; }
   void get_tree_path(int32_t out[2]) const { out[0] = pathReq_; out[1] = 1; }
   void fused_stats(int64_t out[2]) const { out[0] = 0; out[1] = 0; }
   void reset_fused_scales() {}

@@ -12,6 +12,7 @@ from conftest import assert_chain_parity, run_chain
 
 pytestmark = pytest.mark.gpu
 PATHS = ["persistent", "fused", "two-kernel"]
+STREAM_SEEDS = list(range(0, 160, 4))     # the streaming variant of the persistent launch (on request only): every fourth configuration
 
 
 def random_case(seed):
@@ -104,6 +105,19 @@ def test_random_configuration(oracle_lib, hip_lib, seed, path):
         assert_chain_parity(a, b, stan=joint)
     except AssertionError as e:
         raise AssertionError(f"seed {seed} on the {path} path, case {what}: {e}") from e
+
+
+@pytest.mark.parametrize("seed", STREAM_SEEDS)
+def test_random_configuration_on_the_streaming_variant(oracle_lib, hip_lib, seed):
+    args, joint, what = random_case(seed)
+    rt = 0 if joint else 1
+    a = run_chain(oracle_lib, "orc_", args, results_type=rt)
+    b = run_chain(hip_lib, "s4b_", args, results_type=rt, tree_path="stream")
+    assert b["tree_path"][0] == "stream" and (b["tree_path"][1] == "stream" or what["weights"] or what["capacity"] or what["split_probs"]), (what, b["tree_path"])
+    try:
+        assert_chain_parity(a, b, stan=joint)
+    except AssertionError as e:
+        raise AssertionError(f"seed {seed} on the streaming variant, case {what}: {e}") from e
 
 
 # seeds outside 0 .. 159 that once failed (tools/fuzz_range.py campaigns): 280 — k_step proposed for a tree beyond the wave path

@@ -354,7 +354,7 @@ def _k_through_the_shim(R, clib, prefix, n=140):
     assert list(rs) == ref["bartResultNamesWithModeledK"] == ["sigma", "train", "test", "varcount", "k"]
     assert np.array_equal(R.to_numpy(rw["k"]), w["bart"]["k"]) and np.array_equal(R.to_numpy(rs["k"]), r["bart"]["k"])
     assert np.array_equal(R.to_numpy(rs["train"]), r["bart"]["train"]) and np.std(r["bart"]["k"]) > 0
-    R.call("stan4bart_finalize")
+    R.lib.mock_finalize(ptr)      # (what R's garbage collector would run; stan4bart_finalize is the package's unload hook and ends the session's bookkeeping)
     return True
 
 

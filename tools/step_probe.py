@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--trees", type=int, default=200)
     ap.add_argument("--sweeps", type=int, default=3)
     ap.add_argument("--iters", type=int, default=6)
-    ap.add_argument("--path", default="auto", choices=["auto", "two-kernel", "fused", "persistent"])
+    ap.add_argument("--path", default="auto", choices=["auto", "two-kernel", "fused", "persistent", "stream"])
     a = ap.parse_args()
     from stan4bart_amd import RRng, make_sampler_args
     from stan4bart_amd._lib import load_library
