@@ -82,7 +82,7 @@ def test_streaming_sweep_beyond_the_register_capacity(oracle_lib, hip_lib):
     args, _ = friedman_case(n=2_000_000, p=10, T=12, warmup=2, iter=5, ranef=False)
     a = run_chain(oracle_lib, "orc_", args, results_type=1)
     b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path="stream")
-    assert b["tree_path"] == ("stream", "stream") and b["sweep_stats"] == (6, 0)
+    assert b["tree_path"] == ("stream", "stream") and b["sweep_stats"] == (5, 0)      # (the sweep at creation ran on the automatic path)
     assert_chain_parity(a, b, stan=False)
     s = make_sampler(hip_lib, "s4b_", args)
     try:
