@@ -34,6 +34,15 @@ __device__ unsigned long long g_prop[32];
 __device__ unsigned long long g_dec[16];
 #define S4B_DEC_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&g_dec[i], (unsigned long long)wall_clock64()); if ((i) == 0) atomicAdd(&g_dec[15], 1ull); } } while (0)
 #endif
+#ifdef S4B_SWEEP_TIMING
+// (measurement build `make sweeptiming`) time stamps inside decide() of the decider wave of workgroup 100 of k_sweep: sums of absolute clock
+// values per slot ([15] = calls), printed as differences by profile_sweep_persistent; the kernel lives in the dev_sweep.hip translation unit,
+// which owns (and reads back) its own copy of this symbol
+static __device__ unsigned long long g_dec[16];
+// ([i] = sum of (now - entry) over the calls that reach stamp i, [8 + i] = how many did; [0] holds the entry time of the call in flight)
+#define S4B_DEC_T(i) do { if (blockIdx.x == 100 && threadIdx.x == 0) { if ((i) == 0) { g_dec[0] = (unsigned long long)wall_clock64(); atomicAdd(&g_dec[15], 1ull); } \
+                                                                      else { atomicAdd(&g_dec[i], (unsigned long long)wall_clock64() - g_dec[0]); atomicAdd(&g_dec[7 + (i)], 1ull); } } } while (0)
+#endif
 #include "sampler_core.hpp"
 
 namespace s4b {
@@ -2651,6 +2660,10 @@ class DevHip {
       fprintf(stderr, "SWEEP image wave 1, propose() alone by move type (count, us): birth %llu %.2f, death %llu %.2f, swap %llu %.2f, change %llu %.2f; without a valid move %llu; from the start of the drawing step to propose() %.2f us\n",
               h[36], h[36] ? h[24] / (100.0 * h[36]) : 0.0, h[37], h[37] ? h[25] / (100.0 * h[37]) : 0.0, h[38], h[38] ? h[26] / (100.0 * h[38]) : 0.0, h[39], h[39] ? h[27] / (100.0 * h[39]) : 0.0, h[62],
               (h[36] + h[37] + h[38] + h[39]) ? h[63] / (100.0 * (h[36] + h[37] + h[38] + h[39])) : 0.0);
+      { unsigned long long d[16]; sweep_decide_fetch(d);
+        if (d[15]) { auto A = [&](int i) { return d[7 + i] ? (double)d[i] / (100.0 * (double)d[7 + i]) : 0.0; };
+          fprintf(stderr, "SWEEP decide() of the decider wave (%llu calls; %llu with a pending move), us after its entry: bin log-likelihoods %.2f, ratio ready %.2f | all calls: accept test out (generator open, uniform; hooks: early verdict) %.2f, tree updated %.2f, leaf statistics + uniforms %.2f, leaf values %.2f, stored %.2f\n",
+                  d[15], d[8], A(1), A(2), A(3), A(4), A(5), A(6), A(7)); } }
       fprintf(stderr, "SWEEP bins per step (histogram 0..15+):"); for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", h[72 + i]); fprintf(stderr, "\n");
       fprintf(stderr, "SWEEP statistics phase: wave 5 accumulated %.2f, wave-reduced + slots written %.2f, barrier passed %.2f; wave 3 barrier passed %.2f\n", h[30] * k, h[31] * k, h[32] * k, h[33] * k); }
 #endif
