@@ -392,13 +392,24 @@ __device__ __forceinline__ void bins_loglik(const WaveArrD& binCnt, const WaveAr
   out.load(c == 0.0 ? 0.0 : leaf_loglik(binWt.mine(), binSum.mine(), sigma2, prec));
 }
 // value of one leaf from its statistics (weight w, weighted sum s) and the two uniforms of its draw (tree_hd.hpp leaves_draw)
-__device__ __forceinline__ double leaf_value(double w, double s, double u1, double u2, double sigma2, double prec) {
+// (in two halves: the standard normal deviate depends on the two uniforms alone — the persistent sweep has it ready before the statistics arrive)
+__device__ __forceinline__ double leaf_deviate(double u1, double u2) {
   const double BIG = 134217728.0;
-  const double z = r_qnorm(((double)(int)(BIG * u1) + u2) / BIG);
-  const double postPrec = w / sigma2;
-  const double mean = postPrec * (s / w) / (prec + postPrec);
-  const double sd = 1.0 / sqrt(prec + postPrec);
+  return r_qnorm(((double)(int)(BIG * u1) + u2) / BIG);
+}
+// (... and of the posterior only the mean depends on the weighted sum: postPrec = w / sigma2, den = prec + postPrec, sd = 1 / sqrt(den))
+__device__ __forceinline__ double leaf_value_parts(double postPrec, double den, double sd, double w, double s, double z) {
+  const double mean = postPrec * (s / w) / den;
   return mean + sd * z;
+}
+__device__ __forceinline__ double leaf_value_z(double w, double s, double z, double sigma2, double prec) {
+  const double postPrec = w / sigma2;
+  const double den = prec + postPrec;
+  const double sd = 1.0 / sqrt(den);
+  return leaf_value_parts(postPrec, den, sd, w, s, z);
+}
+__device__ __forceinline__ double leaf_value(double w, double s, double u1, double u2, double sigma2, double prec) {
+  return leaf_value_z(w, s, leaf_deviate(u1, u2), sigma2, prec);
 }
 __device__ __forceinline__ void leaves_draw(const WaveArrD& lc, const WaveArrD& ls, const WaveArrD& lw, const WaveArrD& u1, const WaveArrD& u2, int nl,
                                             double sigma2, double prec, WaveArrD& out) {
@@ -2083,7 +2094,7 @@ class DevHip {
         if (getenv("S4B_NOSOLO")) sweepSolo_ = false;
 #endif
         if (sweepOk_) {
-          xbuf_ = zalloc<unsigned long long>((size_t)2 * (XC_RING * XC_BUF_WORDS + XC_ROLL_WORDS));   // two rings (+ the words of the roll call behind each): a launch uses one and clears the other for the next launch
+          xbuf_ = zalloc<unsigned long long>((size_t)2 * (XC_RING_WORDS + XC_ROLL_WORDS));   // two rings (+ the words of the roll call behind each): a launch uses one and clears the other for the next launch
           HIP_OK(hipHostMalloc(&sweepStatus_, 64, hipHostMallocCoherent | hipHostMallocMapped));
           sweepStatus_[0] = -1;
           { void* dp = nullptr; HIP_OK(hipHostGetDevicePointer(&dp, sweepStatus_, 0)); sweepStatusDev_ = (int32_t*)dp; }
@@ -2337,8 +2348,8 @@ class DevHip {
   }
   bool sweep_streams() const { return sweepStream_; }
   SweepArgs sweep_args() {     // (the exchange ring of this launch, the one it clears for the next launch)
-    unsigned long long* cur = xbuf_ + (size_t)xbufParity_ * (XC_RING * XC_BUF_WORDS + XC_ROLL_WORDS);
-    unsigned long long* nxt = xbuf_ + (size_t)(1 - xbufParity_) * (XC_RING * XC_BUF_WORDS + XC_ROLL_WORDS);
+    unsigned long long* cur = xbuf_ + (size_t)xbufParity_ * (XC_RING_WORDS + XC_ROLL_WORDS);
+    unsigned long long* nxt = xbuf_ + (size_t)(1 - xbufParity_) * (XC_RING_WORDS + XC_ROLL_WORDS);
     xbufParity_ ^= 1;
     return SweepArgs{cur, sweepStatusDev_, nxt};
   }
@@ -2609,8 +2620,11 @@ class DevHip {
   // were handed over to k_step so far / all persistent sweeps so far (out[4]), out[6] = wall time per sweep without events
   void profile_sweep_persistent(int nSweeps, int thin, double* out) {
     double sum = 0; int cnt = 0;
+#ifdef S4B_SWEEP_WG
+    { sync(); static unsigned long long dropW[256 * 16]; sweep_wg_fetch(dropW); }
+#endif
 #ifdef S4B_SWEEP_TIMING
-    { sync(); unsigned long long drop[96]; sweep_timing_fetch(drop); }     // (only the sweeps profiled here: not the chain's first ones, which rebuild every structure cache)
+    { sync(); unsigned long long drop[128]; sweep_timing_fetch(drop); }     // (only the sweeps profiled here: not the chain's first ones, which rebuild every structure cache)
 #endif
     for (int sIdx = 0; sIdx < nSweeps * thin; ++sIdx) {
       const int64_t ho = sweepHandOvers_;
@@ -2636,8 +2650,27 @@ class DevHip {
       sync();
       if (ho == sweepHandOvers_) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_)); sum += ms * 1000.0; ++cnt; }
     }
+#ifdef S4B_SWEEP_WG
+    { static unsigned long long w[256 * 16]; sweep_wg_fetch(w);
+      double mn = 1e30, mx = -1e30, sm = 0.0, smn = 1e30, smx = -1e30, xmn = 1e30, xmx = -1e30, xsm = 0.0; int cntW = 0, cntX = 0, argmx = -1, argsmx = -1, argsmn = -1;
+      double refSum = 0.0; int refCnt = 0;
+      for (int b = 0; b < 256; ++b) if (w[b * 16 + 3] && w[b * 16 + 3] == w[3]) { refSum += (double)w[b * 16 + 2] / (double)w[b * 16 + 3]; ++refCnt; }
+      const double ref = refCnt ? refSum / refCnt : 0.0;
+      for (int b = 0; b < 256; ++b) {
+        if (w[b * 16 + 1]) { const double v = (double)w[b * 16] / (100.0 * (double)w[b * 16 + 1]); if (v < mn) mn = v; if (v > mx) { mx = v; argmx = b; } sm += v; ++cntW; }
+        if (w[b * 16 + 3] && w[b * 16 + 3] == w[3]) { const double sk = ((double)w[b * 16 + 2] / (double)w[b * 16 + 3] - ref) / 100.0; if (sk < smn) { smn = sk; argsmn = b; } if (sk > smx) { smx = sk; argsmx = b; } }
+        if (w[b * 16 + 5]) { const double v = (double)w[b * 16 + 4] / (100.0 * (double)w[b * 16 + 5]); if (v < xmn) xmn = v; if (v > xmx) xmx = v; xsm += v; ++cntX; }
+      }
+      fprintf(stderr, "SWEEP exchange, per workgroup (steps whose statistics were published speculatively: %llu): last publish of anybody -> totals seen: min %.2f mean %.2f max %.2f us; first -> last publish %.2f us\n",
+              w[5], xmn, cntX ? xsm / cntX : 0.0, xmx, w[5] ? (double)w[6] / (100.0 * (double)w[5]) : 0.0);
+      { double a8 = 0, a9 = 0, a11 = 0; int c8 = 0;
+        for (int b = 0; b < 255; ++b) if (w[b * 16 + 1]) { const double kq = 1.0 / (100.0 * (double)w[b * 16 + 1]); a8 += (double)w[b * 16 + 8] * kq; a9 += (double)w[b * 16 + 9] * kq; a11 += (double)w[b * 16 + 11] * kq; ++c8; }
+        if (c8) fprintf(stderr, "SWEEP per workgroup (mean over the workgroups), us after the totals were seen, steps that speculate: wave 3's leaf values out %.2f, wave 5 starts the statistics %.2f, wave 4 has published (below), wave 5 through with the step (steps borne out, per speculating step) %.2f\n", a8 / c8, a9 / c8, a11 / c8); }
+      fprintf(stderr, "SWEEP per workgroup: totals seen -> speculative statistics published, us: min %.2f mean %.2f max %.2f (workgroup %d) over %d workgroups; the moment the totals are seen, relative to the mean: %.2f (workgroup %d) .. %.2f us (workgroup %d)\n",
+              mn, cntW ? sm / cntW : 0.0, mx, argmx, cntW, smn, argsmn, smx, argsmx); }
+#endif
 #ifdef S4B_SWEEP_TIMING
-    { unsigned long long h[96]; sweep_timing_fetch(h);
+    { unsigned long long h[128]; sweep_timing_fetch(h);
       const double k = h[0] ? 1.0 / (100.0 * (double)h[0]) : 0.0;
       fprintf(stderr, "SWEEP workgroup 100 (avg over %llu steps, %.2f bins, %llu routed after the decision) | pass waves, us after the previous publish: totals gathered (wave 3) %.2f; wave 4: images there %.2f, routed %.2f, tables + proposal there %.2f, arithmetic done %.2f; published (wave 3) = step %.2f | decider, us after its previous step: totals seen %.2f, verdict %.2f, tables out %.2f, step end %.2f\n",
               h[0], h[0] ? (double)h[7] / (double)h[0] : 0.0, h[8], h[1] * k, h[2] * k, h[3] * k, h[4] * k, h[5] * k, h[6] * k, h[9] * k, h[10] * k, h[11] * k, h[12] * k);
@@ -2645,6 +2678,10 @@ class DevHip {
       { auto A = [&](int i) { return (double)(long long)h[i] * k; };
         fprintf(stderr, "SWEEP timeline of a step, us after this workgroup saw the totals complete: wave 3's leaf values %.2f | decider: sees totals %.2f, verdict + old values out %.2f, new values out %.2f | proposal settled %.2f (x%.2f) | wave 5: (routed %.2f) past foldReady %.2f, old values folded %.2f, tables + proposal seen %.2f, new values folded %.2f, statistics reduced %.2f | wave 4: published %.2f | next totals complete = step %.2f\n",
                 A(51), A(41), A(42), A(43), A(52), 1.0, A(44) - A(40), A(45), A(46), A(47), A(48), A(49), A(50), A(40));
+        { const double ks = h[89] ? 1.0 / (100.0 * (double)h[89]) : 0.0;
+          auto G = [&](int i) { return (double)(long long)h[i] * ks; };
+          fprintf(stderr, "SWEEP speculation: %llu steps published before their verdict, %llu of them borne out | timeline of those steps, us after the totals: wave 5 starts the statistics %.2f, wave 4 has published %.2f, wave 5 past foldReady %.2f, through with the step (borne out) %.2f | all steps: wave 3 past paGo %.2f, decider's decDone %.2f\n",
+                  h[89], h[88], G(90), G(91), G(92), h[88] ? (double)(long long)h[93] / (100.0 * (double)h[88]) : 0.0, (double)(long long)h[94] * k, (double)(long long)h[95] * k); }
         fprintf(stderr, "SWEEP foldReady: stored by wave 0 -> wave 4 / wave 5 past their wait: %.2f / %.2f us; wave 5 still routing when it was stored: %llu steps of %llu, by %.2f us on average\n", A(53), A(54), h[55], h[0], h[55] ? (double)h[56] / (100.0 * (double)h[55]) : 0.0);
         const double kl0 = h[55] ? 1.0 / (100.0 * (double)h[55]) : 0.0;
         const double kl = h[55] ? 1.0 / (100.0 * (double)h[55]) : 0.0, ke = (h[0] - h[55]) ? 1.0 / (100.0 * (double)(h[0] - h[55])) : 0.0;

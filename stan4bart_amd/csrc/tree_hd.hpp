@@ -730,10 +730,12 @@ S4B_HD inline void leaf_stats_draws(const TBL& tb, const CA& ca, const ABIN& bin
 }
 
 struct NoHook { S4B_HD void operator()() const {} };
-struct NoHookI { S4B_HD void operator()(int) const {} };
+struct NoHookI { S4B_HD bool operator()(int) const { return false; } };
 // `drawsDone` is called once the last random number of the step has been consumed (before the batched leaf arithmetic)
 // `beforeDraws` is called once, before the first random number of the step is drawn (the device uses it to finish loading the generator)
-// `afterAccept(acc)` is called as soon as the accept test is out (acc = 0 also for a proposal without a valid move), before the tree is touched
+// `afterAccept(acc)` is called as soon as the accept test is out (acc = 0 also for a proposal without a valid move), before the tree is touched;
+// it returns true when the caller HAS the leaf values of the unchanged tree (acc = 0 only: the persistent sweep computes them beside the accept
+// test) — it has then advanced the generator past their uniforms and sets counts and values itself: statistics, draws and arithmetic are skipped
 template <class TR, class TBL, class AF64, class AI32, class ABIN, class CA, class MV, class RNG, class HOOK = NoHook, class HOOK2 = NoHook, class HOOK3 = NoHookI>
 S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, const MV& m, double sigma, RNG* rng,
                          const Proposal* pr, TBL& tb, const ABIN& binCnt, const ABIN& binSum, const ABIN& binWt, DecideWork<AF64>& wk,
@@ -784,8 +786,15 @@ S4B_HD inline int decide(TR& cur, AF64& mu, AI32& cnt, AF64& muOld, int hwm, con
     beforeDraws();
     acc = (r_unif(rng) < S4B_UNI(ratio)) ? 1 : 0;
   } else beforeDraws();
-  afterAccept(acc);
+  const bool leavesGiven = afterAccept(acc);
   S4B_DEC_T(3);
+  if (leavesGiven) {
+    *accepted = acc;
+    drawsDone();
+    if (rec) { rec->type = prType; rec->status = prStatus == 1 ? acc : -1; rec->var = pr->var; rec->split = pr->split; rec->numLeaves = ca.nl; }
+    S4B_DEC_T(7);
+    return hwm;
+  }
   // sufficient statistics of every leaf of the tree we end up with, in DFS order; the uniforms of the leaf
   // draws are consumed in that order, the (expensive) quantile / posterior arithmetic is batched afterwards
   const bool deathAcc = acc && prType == MOVE_DEATH;
