@@ -2093,6 +2093,8 @@ class DevHip {
 #ifdef S4B_TUNING
         if (getenv("S4B_NOSOLO")) sweepSolo_ = false;
 #endif
+        // no pass thread owns all SW_PF quads (thread 0 of workgroup 0 owns the most): k_sweep_few
+        sweepFew_ = nQuads <= (int64_t)(SW_PF - 1) * (sweepSolo_ ? 1 : a.gridF - 1) * SW_PT;
         if (sweepOk_) {
           xbuf_ = zalloc<unsigned long long>((size_t)2 * (XC_RING_WORDS + XC_ROLL_WORDS));   // two rings (+ the words of the roll call behind each): a launch uses one and clears the other for the next launch
           HIP_OK(hipHostMalloc(&sweepStatus_, 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -2100,6 +2102,7 @@ class DevHip {
           { void* dp = nullptr; HIP_OK(hipHostGetDevicePointer(&dp, sweepStatus_, 0)); sweepStatusDev_ = (int32_t*)dp; }
           HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
           HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
+          HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_few), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
         }
       }
       choose_path();
@@ -2343,6 +2346,7 @@ class DevHip {
   }
   void launch_sweep_kernel() {
     if (sweepStream_) hipLaunchKernelGGL(k_sweep_stream, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
+    else if (sweepFew_) hipLaunchKernelGGL(k_sweep_few, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
     else hipLaunchKernelGGL(k_sweep, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
     ++launches_;
   }
@@ -3022,7 +3026,7 @@ class DevHip {
   int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1; bool binary_ = false;
   size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0; bool useFused_ = false, fusedAuto_ = false, fusedOk_ = false;
   enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_SWEEP = 4, PATH_STREAM = 5 };
-  bool sweepOk_ = false, sweepRegsOk_ = false, sweepStreamOk_ = false, sweepSolo_ = false, sweepStream_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
+  bool sweepOk_ = false, sweepRegsOk_ = false, sweepStreamOk_ = false, sweepSolo_ = false, sweepFew_ = false, sweepStream_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
   int64_t sweepCount_ = 0, sweepHandOvers_ = 0;
   int xbufParity_ = 0; long long dbgSweepNo_ = 0; int sweepGrid_ = 0;
   OffsetArgs pend_; bool pendOffset_ = false, pendSigma_ = false;   // Stan -> BART hand-off calls held for the one-launch form (offset_from_params)
