@@ -353,7 +353,7 @@ def main():
     args.seed = int(rng.sample_int(2147483647, 1)[0])
     sampler = Sampler(lib, prefix, args, rng.state)     # uploads everything: inputs are HBM-resident from here on
     if one_device and world > 1 and not a.emul:
-        sampler.set_device_sharing(world)     # rehearsal mode: all ranks share device 0, a persistent launch could not have it to itself
+        sampler.set_device_sharing(world)     # rehearsal mode: all ranks share device 0 (persistent launches of different processes are sorted out by their roll call)
     sampler.set_tree_path(a.tree_path)
     t_created = time.perf_counter()
     # ---- phase 1 (untimed for the metric): warm-up with adaptation engaged, to the stationary regime

@@ -278,9 +278,12 @@ int S4B_FN(get_trace)(s4b_sampler* s, int64_t cap_records, int32_t* out, int64_t
 /* DFS leaf rank of every training observation in tree t (n int32) */
 int S4B_FN(get_leaf_assignment)(s4b_sampler* s, int32_t tree, int32_t* out);
 /* Not a reference routine.  Hint that `chains` samplers share this sampler's device (R/stan4bart_fit.R:515-533 runs the chains of
- * one fit in parallel workers; here they can be host threads on one GPU).  The default tree update keeps every CU busy with one
- * register-heavy workgroup, which is fastest for a chain that has the device to itself; with three or more chains per device the
- * sampler switches to the two-kernel tree update, which leaves room for the other chains' kernels (higher aggregate rate).  The
+ * one fit in parallel workers; here they can be host threads on one GPU).  Where the persistent sweep applies (set_tree_path) the hint
+ * changes nothing since round 5: samplers of one process take turns on the device, launches of other processes are sorted out by the
+ * roll call at the start of every persistent launch, and the aggregate rate is higher than on the per-tree kernels.
+ * Elsewhere — observation weights, cgm(split.probs), n > 1.04e6 — the fused launch keeps every CU busy with one register-heavy workgroup,
+ * which is fastest for a chain that has the device to itself; with three or more chains per device the sampler switches to the
+ * two-kernel tree update, which leaves room for the other chains' kernels (higher aggregate rate).  The
  * same chain either way: identical tree moves and generator stream, floating-point values equal up to the summation order of the
  * per-bin sums (1e-15 relative).  May be called at any time between runs. */
 int S4B_FN(set_device_sharing)(s4b_sampler* s, int32_t chains);
@@ -288,7 +291,7 @@ int S4B_FN(set_device_sharing)(s4b_sampler* s, int32_t chains);
  * 2 one fused launch per tree (k_step), 4 persistent (k_sweep: ONE launch per sweep, the residual in the registers of the pass waves, bin
  * partials exchanged through order-free integer atomics), 5 persistent with a streaming pass (k_sweep_stream: the same launch, the pass
  * waves read and write the residual per tree; measured slower than 1 / 2 at every size and never chosen automatically).  The automatic
- * choice is 4 wherever it applies — no observation weights, no cgm(split.probs), the chain has the device to itself, at most 16
+ * choice is 4 wherever it applies — no observation weights, no cgm(split.probs), at most 16
  * observations per pass thread (n <= 1 044 480 on 256 compute units) —, else 2 up to n ~ 4e6, else 1.  A request the sampler cannot honour
  * (more than 255 quads per thread for 2, the conditions above for 4 / 5) falls back to the next path down; get_tree_path reports the path
  * in effect.  The same chain on every path (see set_device_sharing).  May be called at any time between runs.

@@ -2599,13 +2599,16 @@ class DevHip {
   bool is_persistent() const { return path_ == PATH_SWEEP || path_ == PATH_STREAM; }
   void choose_path() {
     int want = pathReq_;
-    // automatic: the fused launch while a tree update is latency-bound (few quads per thread), two kernels per tree beyond and when
-    // three or more chains share the device.
-    // The persistent sweep wherever it applies and the chain has the device to itself (its workgroups wait for each other).
+    // automatic: the persistent sweep wherever it applies; else the fused launch while a tree update is latency-bound (few quads per thread),
+    // two kernels per tree beyond and when three or more chains share the device.
     // (The streaming variant of the persistent launch is never the automatic choice: from the four register-heavy pass waves of a compute
     // unit it streams at 3.1 TB/s — 70.8 us per tree update at n = 1e7 against 62.7 for k_tree + k_control, 24.0 against 24.1 for k_step at
     // n = 2e6: DESIGN.md 8, round 5.)
-    if (want == 0) want = sharing_ >= 3 ? PATH_TWO : ((sweepRegsOk_ && sharing_ <= 1) ? PATH_SWEEP : (fusedAuto_ ? PATH_FUSED : PATH_TWO));
+    // (Round 5: the persistent sweep also when chains share the device.  Samplers of one process take turns through the per-device lock, launches of
+    // other processes are sorted out by the roll call, and a chain's host phase runs under another chain's sweep: tools/multi_chain_probe.py at
+    // n = 1e6, aggregate iterations/s with 2 / 3 / 4 / 6 chains: 532 / 461 / 521 / 539 against 393 / 430 / 390 / 444 on the per-tree kernels the hint
+    // used to select.  The hint still picks between those where the persistent sweep does not apply.)
+    if (want == 0) want = sweepRegsOk_ ? PATH_SWEEP : (sharing_ >= 3 ? PATH_TWO : (fusedAuto_ ? PATH_FUSED : PATH_TWO));
     if (want == PATH_SWEEP && !sweepRegsOk_) want = fusedOk_ ? PATH_FUSED : PATH_TWO;
     if (want == PATH_STREAM && !sweepStreamOk_) want = fusedOk_ ? PATH_FUSED : PATH_TWO;
     if (want == PATH_FUSED && !fusedOk_) want = PATH_TWO;

@@ -67,10 +67,11 @@ def test_fused_path_joint_chain(oracle_lib, hip_lib, kw):
 
 
 def test_automatic_path_is_the_persistent_sweep(hip_lib):
-    """no weights, the chain alone on the device, at most 16 observations per pass thread: k_sweep; with weights: the fused launch;
-    three chains on the device: two kernels per tree"""
+    """no weights, at most 16 observations per pass thread: k_sweep — also when chains share the device (round 5: they take turns);
+    with weights: the fused launch, and two kernels per tree when three chains share the device"""
     from conftest import make_sampler
-    for kw, sharing, want in ((dict(), None, "persistent"), (dict(weights=np.random.default_rng(1).random(3000) + 0.5), None, "fused"), (dict(), 3, "two-kernel")):
+    w = np.random.default_rng(1).random(3000) + 0.5
+    for kw, sharing, want in ((dict(), None, "persistent"), (dict(weights=w), None, "fused"), (dict(), 3, "persistent"), (dict(weights=w), 3, "two-kernel")):
         args, _ = friedman_case(n=3000, T=5, warmup=2, iter=4, **kw)
         s = make_sampler(hip_lib, "s4b_", args)
         try:
@@ -244,9 +245,10 @@ def test_trees_with_more_than_128_node_slots(oracle_lib, hip_lib):
 
 @pytest.mark.parametrize("sharing", [(4, None), (None, 4), (4, 1)])
 def test_device_sharing_hint_switches_the_tree_update_without_changing_the_draws(oracle_lib, hip_lib, sharing):
-    """s4b_set_device_sharing: three or more chains per GPU -> two-kernel tree update, fewer -> the fused launch; given before the
-    warm-up, between warm-up and sampling, and back again — the chain is the oracle's either way."""
-    args, _ = friedman_case(n=3000, T=12, warmup=8, iter=16, ranef=True)
+    """s4b_set_device_sharing (where the persistent sweep does not apply — here: observation weights): three or more chains per GPU ->
+    two-kernel tree update, fewer -> the fused launch; given before the warm-up, between warm-up and sampling, and back again — the
+    chain is the oracle's either way."""
+    args, _ = friedman_case(n=3000, T=12, warmup=8, iter=16, ranef=True, weights=np.random.default_rng(7).random(3000) + 0.5)
     a = run_chain(oracle_lib, "orc_", args)
     b = run_chain(hip_lib, "s4b_", args, sharing=sharing)
     assert_chain_parity(a, b)
