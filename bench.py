@@ -24,7 +24,8 @@ Extra objects on the same JSON line:
                       (the reference's cost model); the headline uses sufficient statistics gathered once per iteration
   cpu_baseline        the CPU oracle (oracle/, "port") timed on this box's host, rank 0 at N = 1 only, on the same workload,
                       started from the GPU chain's state after the burn-in (same regime: same leapfrogs per transition)
-  extra_configs       BASELINE configs 1 and 2 (CPU port for both, the HIP path for config 2), small and quick
+  extra_configs       BASELINE configs 1 (CPU port), 2, 4 and 5 (HIP path; each timed in its stationary regime like the headline: warm-up with
+                      adaptation, disengage, sampling iterations, a `stationarity` record and the roofline of the chain that was timed)
 """
 from __future__ import annotations
 
@@ -143,7 +144,7 @@ def sweep_roofline(prof, path, n, trees):
     return rec
 
 
-def target_roofline_leg(lib, n, p, trees, device, sweeps):
+def target_roofline_leg(lib, n, p, trees, device, sweeps, burn_in):
     """north_star's roofline target is quoted at n = 1e7, p = 50, ntree = 200 (larger than the metric's workload): measure
     the same dominant kernel there too, live, on a BART-sized case (Friedman surface, fixed effects X4 + z, numpy's
     generator for the 5e8 uniforms — the R-compatible stream would take minutes on the host and the sweep's cost does
@@ -161,18 +162,24 @@ def target_roofline_leg(lib, n, p, trees, device, sweeps):
     y = (10.0 * np.sin(np.pi * xb[:, 0] * xb[:, 1]) + 20.0 * (xb[:, 2] - 0.5) ** 2 + 5.0 * xb[:, 3] + 10.0 * x4 + 5.0 * z
          + b1[g1 - 1, 0] + b1[g1 - 1, 1] * x4 + 1.1 * g.standard_normal(8)[g2 - 1] + g.standard_normal(n))
     args = make_sampler_args(y, xb, X=np.column_stack([x4, z]), groups=[GroupTerm(g1, x4, "g.1"), GroupTerm(g2, None, "g.2")],
-                             iter=8, warmup=4, keep_fits=False, bart_args={"n.trees": trees}, device=device)
+                             iter=burn_in + 8, warmup=burn_in, keep_fits=False, bart_args={"n.trees": trees}, device=device)
     del xb
     rng = RRng(4321)
     args.seed = int(rng.sample_int(2147483647, 1)[0])
     s = Sampler(lib, "s4b_", args, rng.state)
-    s.run(2, True, 0)
+    # (the sweep is measured on a chain past its burn-in, like the headline: the trees of a young chain are smaller and accept five times as often)
+    t0 = time.perf_counter()
+    s.run(burn_in, True, 0)
+    t_burn = time.perf_counter() - t0
+    s.disengage_adaptation()
     path = s.get_tree_path()[1]
     prof = s.profile_sweep(sweeps)
     lf = s.profile_leapfrog(10)
     rec = sweep_roofline(prof, path, n, trees)
     s.free()
     rec["workload"] = f"Friedman n={n}, p={p}, ntree={trees} (north_star roofline target config)"
+    rec["burn_in"] = burn_in
+    rec["burn_in_seconds"] = t_burn
     rec["hmc"] = {"kernel": "k_stan_fused (direct), K=2, z=3", "bound": "hbm", "achieved": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lf["algorithmic_bytes"] / (lf["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                   "avg_eval_us": lf["kernels_us"], "avg_eval_us_with_result_fetch": lf["with_fetch_us"], "launches_per_eval": lf["launches"],
@@ -215,14 +222,69 @@ def cpu_baseline_from_state(olib, args, state, iters):
     try:
         s.disengage_adaptation()
         s.set_state(state)
+        s.set_trace(True)
         n0 = s.get_nuts_stats()
         t0 = time.perf_counter()
-        s.run(iters, False, 0)
+        out = s.run(iters, False, 0)
         dt = time.perf_counter() - t0
         n1 = s.get_nuts_stats()
+        chain = {"trace": s.get_trace(), "row": out["stan"][:, -1].copy(), "rng": s.get_r_rng_state()}
     finally:
         s.free()
-    return iters / dt, dt, (n1["sum_n_leapfrog"] - n0["sum_n_leapfrog"]) / iters
+    return iters / dt, dt, (n1["sum_n_leapfrog"] - n0["sum_n_leapfrog"]) / iters, chain
+
+
+def chain_check(gpu, cpu, trees):
+    """The CPU leg doubles as a parity check of the regime the headline is measured in: both chains ran the same
+    iterations from the same state.  The first iteration's tree moves must be identical (anything else is a fault of the HIP path or of the
+    oracle: the run stops); over the following iterations NUTS may amplify rounding differences, so the rest is reported."""
+    tg, tc = gpu["trace"], cpu["trace"]
+    first = bool(len(tg) >= trees and len(tc) >= trees and np.array_equal(tg[:trees], tc[:trees]))
+    same = bool(tg.shape == tc.shape and np.array_equal(tg, tc))
+    rec = {"first_iteration_tree_moves_identical": first, "all_tree_moves_identical": same, "tree_moves_compared": int(min(len(tg), len(tc))),
+           "r_generator_state_identical": bool(np.array_equal(gpu["rng"], cpu["rng"])),
+           "nuts_depth_leapfrogs_divergent_identical_last_iteration": bool(np.array_equal(gpu["row"][3:6], cpu["row"][3:6])),
+           "max_rel_diff_stan_row_last_iteration": float(np.max(np.abs(gpu["row"] - cpu["row"]) / (1e-9 + np.abs(cpu["row"]))))}
+    if not first:
+        raise SystemExit("bench.py: from the state after the burn-in the CPU oracle's first iteration does not reproduce the GPU chain's tree moves: " + json.dumps(rec))
+    return rec
+
+
+def stationary_leg(lib, args, seed, burn, timed, nxt, profile_sweeps=0):
+    """One chain in the reference's phase order (R/stan4bart_fit.R:49-51): `burn` warm-up iterations with adaptation, disengage, `timed` sampling
+    iterations timed, `nxt` more to say whether the window was stationary (same leapfrogs per iteration within 20 %: the headline's rule)."""
+    import torch
+    from stan4bart_amd import RRng
+    from stan4bart_amd.abi import Sampler
+    rng = RRng(seed)
+    args.seed = int(rng.sample_int(2147483647, 1)[0])
+    s = Sampler(lib, "s4b_", args, rng.state)
+    try:
+        t0 = time.perf_counter()
+        s.run(burn, True, 0)
+        t_burn = time.perf_counter() - t0
+        s.disengage_adaptation()
+        n0 = s.get_nuts_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.run(timed, False, 0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n1 = s.get_nuts_stats()
+        s.run(nxt, False, 0)
+        n2 = s.get_nuts_stats()
+        lf_win = (n1["sum_n_leapfrog"] - n0["sum_n_leapfrog"]) / timed
+        lf_next = (n2["sum_n_leapfrog"] - n1["sum_n_leapfrog"]) / nxt
+        rec = {"gpu_iters_per_sec": timed / dt, "ms_per_step": 1e3 * dt / timed, "gpu_seconds": dt, "n_leapfrog_per_step": lf_win, "hmc_mode": s.get_hmc_mode(),
+               "tree_path": s.get_tree_path()[1],
+               "stationarity": {"burn_in": burn, "burn_in_seconds": t_burn, "timed_iterations": timed, "n_leapfrog_per_step_timed_window": lf_win,
+                                "n_leapfrog_per_step_next_iterations": lf_next, "next_iterations": nxt, "ratio": lf_win / lf_next if lf_next else None,
+                                "stationary": bool(lf_next and 0.8 <= lf_win / lf_next <= 1.25)}}
+        prof = s.profile_sweep(profile_sweeps) if profile_sweeps else None
+        lf = s.profile_leapfrog(5) if profile_sweeps else None
+    finally:
+        s.free()
+    return rec, prof, lf
 
 
 def reference_r_leg(n, p, trees, iters):
@@ -296,6 +358,8 @@ def main():
     ap.add_argument("--profile-sweeps", type=int, default=2)
     ap.add_argument("--tree-path", default="auto", choices=["auto", "two-kernel", "fused", "persistent", "stream"])
     ap.add_argument("--c5-n", type=int, default=10_000_000, help="observations of the BASELINE config 5 leg of extra_configs (0 = skip; N = 1 only)")
+    ap.add_argument("--target-burn-in", type=int, default=300, help="warm-up iterations of the n = --target-n leg before its sweeps are profiled")
+    ap.add_argument("--c5-burn-in", type=int, default=300, help="warm-up iterations of the config 5 leg before its 20 timed sampling iterations")
     ap.add_argument("--target-n", type=int, default=10_000_000,
                     help="also measure the sweep kernel at north_star's roofline-target size (0 = skip; N = 1 only)")
     ap.add_argument("--emul", action="store_true",
@@ -436,10 +500,20 @@ def main():
         if lib.s4b_stream_probe(ctypes.c_int32(local_rank), ctypes.c_int64(1 << 27), ctypes.c_int32(5), po) == 0:
             probe = {"read_GBs": po[0], "update_in_place_GBs": po[1]}
     fused_stats = sampler.get_fused_stats()
+    sweep_spec, sweep_busy = (sampler.get_sweep_spec(), sampler.get_sweep_busy()) if not a.emul else ((0, 0, 0, 0), 0)
+    gpu_chain = None
+    if state_after_burn_in is not None and not a.no_cpu_baseline:
+        # the iterations the CPU leg below runs from the same state, once more on the GPU with the tree-move trace on (untimed)
+        sampler.set_state(state_after_burn_in)
+        sampler.set_hmc_mode(hmc_mode)
+        sampler.set_trace(True)
+        og = sampler.run(a.cpu_iters, False, 0)
+        gpu_chain = {"trace": sampler.get_trace(), "row": og["stan"][:, -1].copy(), "rng": sampler.get_r_rng_state()}
+        sampler.set_trace(False)
     sampler.free()
     target = None
     if world == 1 and a.target_n > 0 and a.target_n != a.n and not a.emul:
-        target = target_roofline_leg(lib, a.target_n, a.p, a.trees, local_rank, a.profile_sweeps)
+        target = target_roofline_leg(lib, a.target_n, a.p, a.trees, local_rank, a.profile_sweeps, a.target_burn_in)
 
     if rank == 0:
         n = a.n
@@ -464,6 +538,8 @@ def main():
                        "divergent_timed": int(s1["divergent"] - s0["divergent"]),
                        "gradient_evals_timed": int(c1[0] - c0[0]), "tree_updates_timed": int(c1[1] - c0[1]),
                        "fused_sum_evaluations": fused_stats[0], "fused_sum_fallbacks_to_doubles": fused_stats[1],
+                       "persistent_launches": {"ran": sweep_spec[0], "tree_updates_inside": sweep_spec[1], "published_before_the_verdict": sweep_spec[2],
+                                               "borne_out": sweep_spec[3], "found_the_device_busy": sweep_busy},
                        "sigma_last": [float(s[0]) for s in summ],
                        "host_cores_per_rank": [int(s[4]) for s in summ],
                        "setup_seconds_per_rank": {"design (rank 0 generates, others load)": [float(s[1]) for s in summ],
@@ -542,11 +618,12 @@ def main():
             if probe:
                 target["frac_of_measured_update_stream"] = target["achieved"] / probe["update_in_place_GBs"]
             rec["roofline_target_config"] = target
-        if state_after_burn_in is not None:
+        if state_after_burn_in is not None and not a.no_cpu_baseline:
             olib = oracle_lib()
             cargs = case_from_design(d, a.p, a.trees, 0, a.burn_in, total)
-            v, secs, lfc = cpu_baseline_from_state(olib, cargs, state_after_burn_in, a.cpu_iters)
+            v, secs, lfc, cpu_chain = cpu_baseline_from_state(olib, cargs, state_after_burn_in, a.cpu_iters)
             rec["cpu_baseline"] = {"value": v, "unit": "Gibbs iterations/s/chain", "cores": 1, "kind": "port",
+                                   "same_chain_as_the_gpu": chain_check(gpu_chain, cpu_chain, a.trees),
                                    "sample": f"same workload (n={n}, p={a.p}, ntree={a.trees}), {a.cpu_iters} sampling-phase Gibbs iterations started from the GPU chain's state "
                                              f"after the burn-in (adapted step size and metric; {lfc:.1f} leapfrogs per iteration, each O(N) as in the reference), "
                                              f"{secs:.1f} s of single-thread CPU time, host has {os.cpu_count()} cores",
@@ -564,57 +641,47 @@ def main():
             v1, s1c = time_chain(olib, "orc_", a1, 12345, 100, 300)
             extra["config1"] = {"workload": "Friedman n=100, ntree=50, (1|g.1)+(1|g.2) (BASELINE config 1, CPU plumbing case)",
                                 "cpu_port_iters_per_sec": v1, "cpu_seconds": s1c}
+            # configs 2, 4, 5 on the GPU: each in the reference's phase order (warm-up with adaptation, disengage, sample) and timed in its
+            # STATIONARY regime like the headline, with its own `stationarity` record and the roofline of the chain that was timed
             d2 = generate_friedman_data(100_000, ranef=False, causal=True, p=10)
             a2c = case_from_design(d2, 10, 200, 0, 0, 40, ranef=False)
             v2c, s2c = time_chain(olib, "orc_", a2c, 12345, 2, 30)
-            a2g = case_from_design(d2, 10, 200, local_rank, 0, 400, ranef=False)
-            v2g, s2g = time_chain(lib, "s4b_", a2g, 12345, 100, 200)
-            extra["config2"] = {"workload": "Friedman n=1e5, p=10, ntree=200, fixed effects only (BASELINE config 2)",
-                                "gpu_iters_per_sec": v2g, "gpu_seconds": s2g, "cpu_port_iters_per_sec": v2c, "cpu_seconds": s2c, "cpu_cores": 1}
+            a2g = case_from_design(d2, 10, 200, local_rank, 1000, 1400, ranef=False)
+            r2, p2, _ = stationary_leg(lib, a2g, 12345, 1000, 200, 100, profile_sweeps=a.profile_sweeps)
+            r2.update({"workload": "Friedman n=1e5, p=10, ntree=200, fixed effects only (BASELINE config 2)",
+                       "cpu_port_iters_per_sec": v2c, "cpu_seconds": s2c, "cpu_cores": 1, "cpu_port_note": "30 warm-up-phase iterations from the start of a chain",
+                       "roofline_tree_kernel": sweep_roofline(p2, r2["tree_path"], 100_000, 200)})
+            extra["config2"] = r2
             # BASELINE config 4 at its shape: the 747 x 25 IHDP covariates, 26-level group with a random slope on the treatment,
             # binary outcome / probit link (the latents are drawn on the device from R's stream), counterfactual test rows
-            from stan4bart_amd.abi import Sampler as _S
             from stan4bart_amd.cases import c5_case, ihdp_case
-            a4 = ihdp_case(warmup=200, iter=600, T=75)
+            a4 = ihdp_case(warmup=1000, iter=1600, T=75)
             a4.device = local_rank
-            v4, s4 = time_chain(lib, "s4b_", a4, 12345, 200, 400)
-            extra["config4"] = {"workload": "IHDP shape: n=747, 25 covariates + treatment, ntree=75, (1+z|g1) with 26 levels, binary outcome / probit link, "
-                                            "747 counterfactual test rows (BASELINE config 4; the outcome is this repository's surrogate, DESIGN.md 7)",
-                                "gpu_iters_per_sec": v4, "gpu_seconds": s4}
+            r4, p4, _ = stationary_leg(lib, a4, 12345, 1000, 400, 100, profile_sweeps=a.profile_sweeps)
+            r4.update({"workload": "IHDP shape: n=747, 25 covariates + treatment, ntree=75, (1+z|g1) with 26 levels, binary outcome / probit link, "
+                                   "747 counterfactual test rows (BASELINE config 4; the outcome is this repository's surrogate, DESIGN.md 7)",
+                       "roofline_tree_kernel": sweep_roofline(p4, r4["tree_path"], 747, 75)})
+            extra["config4"] = r4
             if a.c5_n > 0:
                 # BASELINE config 5 ("HBM-roofline run"): n = 1e7, P = 100, ntree = 400, 200 groups with random slopes (q = 400, z = 2)
                 t5 = time.perf_counter()
-                a5, xb5 = c5_case(a.c5_n, warmup=4, iter=12, keep_fits=False, device=local_rank)
+                a5, xb5 = c5_case(a.c5_n, warmup=a.c5_burn_in, iter=a.c5_burn_in + 60, keep_fits=False, device=local_rank)
                 del xb5
-                r5 = RRng(777)
-                a5.seed = int(r5.sample_int(2147483647, 1)[0])
-                s5 = _S(lib, "s4b_", a5, r5.state)
                 t5c = time.perf_counter()
-                s5.run(4, True, 0)
-                s5.disengage_adaptation()
-                n0 = s5.get_nuts_stats()
-                t0 = time.perf_counter()
-                s5.run(6, False, 0)
-                torch.cuda.synchronize()
-                d5 = time.perf_counter() - t0
-                n1 = s5.get_nuts_stats()
-                path5 = s5.get_tree_path()[1]
-                p5 = s5.profile_sweep(1)
-                l5 = s5.profile_leapfrog(5)
-                s5.free()
-                rf5 = sweep_roofline(p5, path5, a.c5_n, 400)
+                r5, p5, l5 = stationary_leg(lib, a5, 777, a.c5_burn_in, 20, 20, profile_sweeps=1)
+                rf5 = sweep_roofline(p5, r5["tree_path"], a.c5_n, 400)
                 K5, z5 = 2, 2
                 read5 = float(a.c5_n) * (8 * K5 + 12 * z5 + 8)
-                extra["config5"] = {"workload": f"n={a.c5_n}, P=100, ntree=400, (1+X4|g.1) with 200 groups: q=400, z=2 (BASELINE config 5)",
-                                    "gpu_iters_per_sec": 6 / d5, "ms_per_step": 1e3 * d5 / 6, "n_leapfrog_per_step": (n1["sum_n_leapfrog"] - n0["sum_n_leapfrog"]) / 6,
-                                    "setup_seconds": {"data + binning on the host": t5c - t5}, "hmc_mode": 0,
-                                    "roofline_tree_kernel": rf5,
-                                    "roofline_hmc": {"kernel": "k_stan_fused (direct), K=2, z=2, 400-column Z'e histogram in LDS", "avg_eval_us": l5["kernels_us"],
-                                                     "avg_eval_us_with_result_fetch": l5["with_fetch_us"],
-                                                     "algorithmic_bytes_per_eval": l5["algorithmic_bytes"],
-                                                     "frac": l5["algorithmic_bytes"] / (l5["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                                     "bytes_the_kernel_reads_per_eval": read5,
-                                                     "frac_against_bytes_read": read5 / (l5["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}}
+                r5.update({"workload": f"n={a.c5_n}, P=100, ntree=400, (1+X4|g.1) with 200 groups: q=400, z=2 (BASELINE config 5)",
+                           "setup_seconds": {"data + binning on the host": t5c - t5},
+                           "roofline_tree_kernel": rf5,
+                           "roofline_hmc": {"kernel": "k_stan_fused (direct), K=2, z=2, 400-column Z'e histogram in LDS", "avg_eval_us": l5["kernels_us"],
+                                            "avg_eval_us_with_result_fetch": l5["with_fetch_us"],
+                                            "algorithmic_bytes_per_eval": l5["algorithmic_bytes"],
+                                            "frac": l5["algorithmic_bytes"] / (l5["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                            "bytes_the_kernel_reads_per_eval": read5,
+                                            "frac_against_bytes_read": read5 / (l5["kernels_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}})
+                extra["config5"] = r5
             rec["extra_configs"] = extra
         if rec["n_gpus"] != a.gpus:
             raise SystemExit(f"internal: n_gpus {rec['n_gpus']} != --gpus {a.gpus}")

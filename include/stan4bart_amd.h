@@ -36,6 +36,9 @@
 extern "C" {
 #endif
 
+/* revision of the struct layouts below; s4b_bart_control.interface_version must carry it (checked by create()) */
+#define S4B_INTERFACE_VERSION 6
+
 typedef struct s4b_sampler s4b_sampler; /* reference: `Sampler`, src/init.cpp:124-173, held in an externalptr */
 
 /* dbartsControl + dbartsModel fields the reference sets (R/stan4bart_fit.R:436-479) */
@@ -54,7 +57,10 @@ typedef struct {
                               * tests/testthat/test-09-bartArgs.R:20).  Tree updates then run on the two-kernel path.           */
   int32_t use_quantiles;     /* dbartsControl(useQuantiles = ) through bart_args (R/stan4bart_fit.R:440-444): 0 uniform cut points
                               * between the column extremes, 1 cut points from the distinct values (n_cuts is then a maximum)    */
-  int32_t reserved;
+  int32_t interface_version; /* must be S4B_INTERFACE_VERSION: create() refuses anything else.  This struct and s4b_results have grown fields over the revisions
+                              * (k_hyper_*, bart_k) and carry no size field: a caller compiled against an older header would pass short structs, and
+                              * run() would read past their end.  The word was `reserved` (0) in those headers, so such a caller is refused at
+                              * create() — before any of the newer fields is read — instead of being served garbage. */
   /* normal(k = chi(degreesOfFreedom, scale)) — reference R/stan4bart.R:202 ("allow calls like bart_args = list(k = chi(2, Inf))"),
    * R/stan4bart_fit.R:460-465, tests/testthat/test-09-bartArgs.R:32; model@node.hyperprior, `kPrior->isFixed` src/init.cpp:272,731.
    * k_hyper_df <= 0: k is fixed (`k` above).  k_hyper_df > 0: k is a parameter with prior density k^(df - 1) exp(-k^2 / (2 scale^2))
@@ -304,9 +310,14 @@ int S4B_FN(get_counters)(s4b_sampler* s, int64_t out[3]);
 /* diagnostics of the one-launch O(N) sums of the Stan block (k_stan_fused): out = {evaluations, evaluations repeated in plain
  * doubles because the fixed-point range check failed (first evaluation, rescaled response, trajectory far outside the typical set)} */
 int S4B_FN(get_fused_stats)(s4b_sampler* s, int64_t out[2]);
-/* persistent tree path only (zeros otherwise): out = {sweeps run by k_sweep, of which handed over to k_step launches part-way because a
+/* persistent tree path only (zeros otherwise): out = {sweeps run while the persistent path was in effect — the ones a busy device sent to
+ * k_step launches (get_sweep_busy and the back-off after it) included —, of which handed over to k_step launches part-way because a
  * tree outgrew the 64 node slots of the wave-register control path} since creation */
 int S4B_FN(get_sweep_stats)(s4b_sampler* s, int64_t out[2]);
+/* persistent tree path only (zeros otherwise), since creation: out = {persistent launches that ran (roll call passed), tree updates
+ * decided inside them, steps whose bin statistics were published BEFORE the verdict of the tree before (speculation), steps
+ * of those whose verdict bore the speculation out} */
+int S4B_FN(get_sweep_spec)(s4b_sampler* s, int64_t out[4]);
 /* persistent tree path only (zero otherwise): persistent launches that found the device shared (not every workgroup of the launch became
  * resident within 200 us: somebody else's kernels held compute units).  Such a launch changes nothing; its sweep ran as k_step launches and
  * so do the next 16, 32, ... sweeps before the persistent launch is tried again.  (The reference's chain fan-out starts one worker process
@@ -337,6 +348,11 @@ int S4B_FN(stream_probe)(int32_t device, int64_t n_doubles, int32_t reps, double
  * out[0] us per evaluation (kernels), out[1] us including the result fetch, out[2] launches per evaluation, out[3] N,
  * out[4] algorithmic bytes per evaluation N (8K + 12z + 20) (SURVEY §8d B_lf) */
 int S4B_FN(profile_leapfrog)(s4b_sampler* s, int32_t n_evals, double out[8]);
+
+/* TEST HOOK (no reference counterpart; off by default): hook 1, value k > 0 — every k-th persistent launch of this sampler finds the roll call
+ * of its launch already decided "device busy" (what a launch sees that shares the device with another process's kernels), so that the busy
+ * fallback of the persistent path runs under the parity tests without a second process; value 0 switches it off.  Other hooks are rejected. */
+int S4B_FN(set_test_hook)(s4b_sampler* s, int32_t hook, int64_t value);
 
 /* finalizer of the externalptr — src/init.cpp:1152-1165 */
 void S4B_FN(free)(s4b_sampler* s);

@@ -95,6 +95,7 @@ int orc_create(const s4b_bart_control* bc, const s4b_bart_data* bd, const s4b_st
                const s4b_stan_control* sc, const s4b_common_control* cc, const uint32_t* r_rng_state,
                s4b_sampler** out) {
   try {
+    if (bc->interface_version != S4B_INTERFACE_VERSION) throw std::invalid_argument("s4b_bart_control.interface_version must be S4B_INTERFACE_VERSION");
     std::unique_ptr<s4b_sampler> sp(new s4b_sampler);
     s4b_sampler& s = *sp;
     s.warmup = cc->warmup; s.iter = cc->iter; s.verbose = cc->verbose; s.refresh = cc->refresh;
@@ -493,10 +494,12 @@ int orc_set_state(s4b_sampler* s, const void* buf, int64_t size) {
     if (hd.magic != S4B_STATE_MAGIC || hd.version != 1u) throw std::invalid_argument("not a stan4bart sampler state");
     if (hd.n != (int64_t)n || hd.n_trees != bf.cfg.numTrees || hd.num_unconstrained != D || (hd.is_binary != 0) != s->binary || hd.p != (int32_t)bf.p)
       throw std::invalid_argument("sampler state: dimensions do not match this sampler");
-    if (bf.cfg.kDf > 0.0) {
+    {
       double kk; std::memcpy(&kk, &hd.reserved[0], 8);
-      if (!(kk > 0.0) || !std::isfinite(kk)) throw std::invalid_argument("sampler state: k must be positive and finite");
-      bf.cfg.k = kk;
+      if (bf.cfg.kDf > 0.0) {
+        if (!(kk > 0.0) || !std::isfinite(kk)) throw std::invalid_argument("sampler state: k must be positive and finite");
+        bf.cfg.k = kk;
+      } else if (kk != 0.0) throw std::invalid_argument("sampler state: it carries the value of a modeled k, this sampler's k is fixed");
     }
     in.get(ns.cont_params.data(), (size_t)D); in.get(ns.inv_metric.data(), (size_t)D); in.get(ns.wf_m.data(), (size_t)D); in.get(ns.wf_m2.data(), (size_t)D);
     double sc6[6]; in.get(sc6, 6);

@@ -261,6 +261,7 @@ void unpack_bart(SEXP control, SEXP data, SEXP model, s4b_bart_control& bc, s4b_
     }
   }
   // dbartsControl(useQuantiles = ) travels through bart_args (R/stan4bart_fit.R:440-444)
+  bc.interface_version = S4B_INTERFACE_VERSION;
   bc.use_quantiles = (has_slot(control, "useQuantiles") && Rf_asLogical(slot(control, "useQuantiles")) == TRUE) ? 1 : 0;
   bc.node_scale = Rf_asReal(slot(model, "node.scale"));
   bc.birth_or_death_prob = Rf_asReal(slot(model, "p.birth_death")); bc.swap_prob = Rf_asReal(slot(model, "p.swap"));

@@ -13,6 +13,7 @@ from typing import Callable, Optional, Sequence
 
 import numpy as np
 
+INTERFACE_VERSION = 6     # S4B_INTERFACE_VERSION of include/stan4bart_amd.h (tests/test_host_logic.py compares the two)
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint32_p = C.POINTER(C.c_uint32)
@@ -24,7 +25,7 @@ class BartControl(C.Structure):
                 ("base", C.c_double), ("power", C.c_double), ("k", C.c_double), ("node_scale", C.c_double),
                 ("birth_or_death_prob", C.c_double), ("swap_prob", C.c_double),
                 ("change_prob", C.c_double), ("birth_prob", C.c_double),
-                ("split_probs", c_double_p), ("use_quantiles", C.c_int32), ("reserved", C.c_int32),
+                ("split_probs", c_double_p), ("use_quantiles", C.c_int32), ("interface_version", C.c_int32),
                 ("k_hyper_df", C.c_double), ("k_hyper_scale", C.c_double)]
 
 
@@ -198,7 +199,7 @@ class Sampler:
         bc = BartControl(n_trees=a.n_trees, n_thin=a.n_thin, keep_trees=int(a.keep_trees),
                          node_capacity=a.node_capacity, base=a.base, power=a.power, k=a.k, node_scale=ns,
                          birth_or_death_prob=pp[0], swap_prob=pp[1], change_prob=pp[2], birth_prob=pp[3],
-                         use_quantiles=int(bool(a.use_quantiles)),
+                         use_quantiles=int(bool(a.use_quantiles)), interface_version=INTERFACE_VERSION,
                          k_hyper_df=0.0 if a.k_hyper is None else float(a.k_hyper[0]),
                          k_hyper_scale=float("inf") if a.k_hyper is None else float(a.k_hyper[1]))
         self.k_modeled = a.k_hyper is not None
@@ -289,7 +290,7 @@ class Sampler:
             "get_leaf_assignment": [vp, i32, ip], "get_counters": [vp, C.POINTER(i64)], "get_nuts_stats": [vp, dp],
             "profile_sweep": [vp, i32, dp], "profile_leapfrog": [vp, i32, dp],
             "set_progress": [vp, PROGRESS, vp], "set_device_sharing": [vp, i32],
-            "set_tree_path": [vp, i32], "get_tree_path": [vp, ip], "get_fused_stats": [vp, C.POINTER(i64)], "get_sweep_stats": [vp, C.POINTER(i64)], "get_sweep_busy": [vp, C.POINTER(i64)], "set_hmc_mode": [vp, i32], "get_hmc_mode": [vp, ip],
+            "set_tree_path": [vp, i32], "get_tree_path": [vp, ip], "get_fused_stats": [vp, C.POINTER(i64)], "get_sweep_stats": [vp, C.POINTER(i64)], "get_sweep_busy": [vp, C.POINTER(i64)], "get_sweep_spec": [vp, C.POINTER(i64)], "set_test_hook": [vp, i32, i64], "set_hmc_mode": [vp, i32], "get_hmc_mode": [vp, ip],
         }
         for name, argtypes in sig.items():
             fn = getattr(self._lib, self._pfx + name, None)
@@ -495,6 +496,19 @@ class Sampler:
         out = (C.c_int64 * 2)()
         self._check(fn(self._h, out))
         return (int(out[0]), int(out[1]))
+
+    def get_sweep_spec(self):
+        """(persistent launches that ran, tree updates decided inside them, steps published before their verdict, steps borne out) since creation."""
+        fn = getattr(self._lib, self._pfx + "get_sweep_spec", None)
+        if fn is None:
+            return (0, 0, 0, 0)
+        out = (C.c_int64 * 4)()
+        self._check(fn(self._h, out))
+        return tuple(int(v) for v in out)
+
+    def set_test_hook(self, hook: int, value: int):
+        """TEST HOOK (include/stan4bart_amd.h): hook 1, value k — every k-th persistent launch reports a busy device (0 = off)."""
+        self._check(self._f("set_test_hook")(self._h, int(hook), int(value)))
 
     def get_sweep_busy(self) -> int:
         """Persistent launches that found the device shared (roll call failed; their sweeps ran as k_step launches) since creation."""

@@ -2335,11 +2335,27 @@ class DevHip {
   // sweepBackoff_ sweeps run as k_step launches, then the persistent launch is tried again; every further failure doubles the pause.
   int64_t sweepBusyUntil_ = 0, sweepBusy_ = 0; int sweepBackoff_ = 16;
   bool persistent_now() const { return sweepCount_ >= sweepBusyUntil_; }
+  // TEST HOOK (s4b_set_test_hook 1): every k-th persistent launch finds the decision word of its roll call already at BUSY — what a launch sees
+  // that shares the device with somebody else's kernels — so that the busy fallback (the sweep rerun as per-tree launches, the back-off, the Stan
+  // inputs formed again) runs under the parity tests without a second process.  0 = off.
+  int64_t hookBusyEvery_ = 0, hookLaunchNo_ = 0;
+  void set_test_hook(int hook, int64_t value) {
+    if (hook != 1 || value < 0) throw std::invalid_argument("set_test_hook: hook 1 (every k-th persistent launch reports a busy device; 0 = off) is the only one");
+    hookBusyEvery_ = value; hookLaunchNo_ = 0;
+  }
+  void hook_before_persistent_launch() {
+    if (hookBusyEvery_ <= 0 || sweepGrid_ == 1) return;        // (a one-workgroup launch holds no roll call)
+    if (++hookLaunchNo_ % hookBusyEvery_ != 0) return;
+    unsigned long long* cur = xbuf_ + (size_t)xbufParity_ * (XC_RING_WORDS + XC_ROLL_WORDS);      // (the ring sweep_args() hands to the launch that follows)
+    static const unsigned long long busy = SW_ROLL_BUSY;
+    HIP_OK(hipMemcpyAsync(cur + XC_RING_WORDS + 1, &busy, 8, hipMemcpyHostToDevice, stream_));
+  }
   void sweep_persistent_launch() {
     if (sweepLock_.owns_lock()) sweepLock_.unlock();      // (a previous launch whose end an exception kept us from seeing)
     sweepLock_ = std::unique_lock<std::mutex>(sweep_mutex(device_));
     for (int i = 0; i < 16; ++i) sweepStatus_[i] = 0;
     sweepStatus_[0] = -1;
+    hook_before_persistent_launch();
     launch_sweep_kernel();
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sweepLock_.unlock(); HIP_OK(e); }
@@ -2363,6 +2379,7 @@ class DevHip {
     if (sweepLock_.owns_lock()) sweepLock_.unlock();
     const int st = sweepStatus_[0];
     ++sweepCount_;
+    count_persistent_launch(st);
     if (st == T_ + 1) { if (sweepBackoff_ > 16 && sweepCount_ > sweepBusyUntil_ + 64) sweepBackoff_ = 16; return true; }
     if (st == -2) {       // roll call failed: the device is shared right now; nothing of the chain was touched
       ++sweepBusy_;
@@ -2386,9 +2403,22 @@ class DevHip {
     if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_));
     return false;
   }
-  void sweep_fused_or_two_one() { sweep_fused_one(); }      // (a sampler on the persistent path always has the fused launch: sweepOk_ implies fusedOk_)
+  // The sweep of a persistent launch that found the device shared (and the sweeps of the back-off after it).  With three or more chains on the device
+  // (s4b_set_device_sharing) the two-kernel tree update: the fused launch keeps every compute unit busy with one workgroup of 8 register-heavy
+  // waves and leaves no room for the other chains' kernels (measured at n = 1e6, 4 chains: 512 against 425 iterations/s in aggregate) — the same
+  // rule choose_path applies where the persistent sweep does not exist.  Both start from and leave the state every path shares between sweeps.
+  void sweep_fused_or_two_one() { if (sharing_ >= 3) sweep_two_one(); else sweep_fused_one(); }
+  void sweep_two_one() {
+    hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, -1, 0); ++launches_;
+    for (int t = 0; t < T_; ++t) {
+      launch_tree(t);
+      hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, t, t + 1 < T_ ? t + 1 : -1);
+      launches_ += 2;
+    }
+    hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, T_ - 1); ++launches_;
+  }
   void sweep_persistent_one() {
-    if (!persistent_now()) { ++sweepCount_; sweep_fused_one(); return; }
+    if (!persistent_now()) { ++sweepCount_; sweep_fused_or_two_one(); return; }
     TurnGuard turn(*this);
     sweep_persistent_launch();
     HIP_OK(hipStreamSynchronize(stream_));
@@ -2402,7 +2432,7 @@ class DevHip {
   void sweep_and_stan_inputs(int thin, int mode, bool wantTrain, double* cX, double* cZ, double* s0, double* trainOut) {
     if (!is_persistent() || binary_ || thin < 1 || !persistent_now() || kModeled_) { sweep(thin); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); return; }
     for (int k = 0; k + 1 < thin; ++k) sweep_persistent_one();
-    if (!persistent_now()) { ++sweepCount_; sweep_fused_one(); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); return; }
+    if (!persistent_now()) { ++sweepCount_; sweep_fused_or_two_one(); stan_inputs(mode, wantTrain, cX, cZ, s0, trainOut); return; }
     TurnGuard turn(*this);
     sweep_persistent_launch();
     const FxHostState saved = fx_host_state();
@@ -2506,13 +2536,7 @@ class DevHip {
     }
     for (int k = 0; k < thin; ++k) {
       // per tree: one fused O(N) kernel (finish tree t-1, statistics of tree t) + one control kernel
-      hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, -1, 0); ++launches_;
-      for (int t = 0; t < T_; ++t) {
-        launch_tree(t);
-        hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, t, t + 1 < T_ ? t + 1 : -1);
-        launches_ += 2;
-      }
-      hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, T_ - 1); ++launches_;
+      sweep_two_one();
       if (binary_ && withLatents) launch_latents();
     }
   }
@@ -2530,6 +2554,7 @@ class DevHip {
       }
       if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_));
       if (binary_) launch_latents();
+      if (kModeled_) draw_k();      // (a profiled sweep is a sweep of the chain: trees, latents, k — sweep_impl's order)
       sync();
       for (int t = 0; t <= T_; ++t) {
         float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[(size_t)2 * t], ev[(size_t)2 * t + 1]));
@@ -2638,14 +2663,15 @@ class DevHip {
       {
         std::lock_guard<std::mutex> turn(sweep_mutex(device_));
         HIP_OK(hipEventRecord(evStart_, stream_));
-        sweepStatus_[0] = -1;
+        sweepStatus_[0] = -1; sweepStatus_[13] = 0; sweepStatus_[14] = 0;
         launch_sweep_kernel();
         HIP_OK(hipEventRecord(evStop_, stream_));
         sync();
       }
       const int st = sweepStatus_[0];
       ++sweepCount_;
-      if (st == -2) { ++sweepBusy_; sweep_fused_one(); if (binary_) launch_latents(); sync(); continue; }     // (roll call failed: the device is shared; not a sample of the persistent launch)
+      count_persistent_launch(st);
+      if (st == -2) { ++sweepBusy_; sweep_fused_or_two_one(); if (binary_) launch_latents(); if (kModeled_) draw_k(); sync(); continue; }     // (roll call failed: the device is shared; not a sample of the persistent launch)
       if (st < 0 || st > T_ + 1) throw std::runtime_error("persistent tree sweep: the launch did not complete");
       if (st != T_ + 1) {
         ++sweepHandOvers_;
@@ -2654,6 +2680,7 @@ class DevHip {
                if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_)); }
       }
       if (binary_) launch_latents();
+      if (kModeled_) draw_k();
       sync();
       if (ho == sweepHandOvers_) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, evStart_, evStop_)); sum += ms * 1000.0; ++cnt; }
     }
@@ -2742,6 +2769,8 @@ class DevHip {
         HIP_OK(hipEventRecord(ev[e++], stream_));
         hipLaunchKernelGGL(k_apply, dim3(a_.grid), dim3(BLOCK), ldsApply_, stream_, a_, T_ - 1); ++launches_;
         HIP_OK(hipEventRecord(ev[e++], stream_));
+        if (binary_) launch_latents();
+        if (kModeled_) draw_k();
       }
       sync();
       for (size_t i = 0; i + 1 < e; i += 2) {
@@ -2928,6 +2957,13 @@ class DevHip {
   // the chain that was never interrupted: bit-identical, not just equal to 2^-67.
   void reset_fused_scales() { fxExp_[0] = fxExp_[1] = fxExp_[2] = 0; fxLastBad_ = -2; fxTinyFail_ = false; }
   void sweep_stats(int64_t out[2]) const { out[0] = sweepCount_; out[1] = sweepHandOvers_; }
+  // {persistent launches that ran (roll call passed), tree updates decided inside them, steps whose statistics went out before their verdict, steps borne out}
+  void sweep_spec(int64_t out[4]) const { out[0] = sweepLaunchesRun_; out[1] = sweepTreesInside_; out[2] = sweepSpecSteps_; out[3] = sweepSpecOk_; }
+  void count_persistent_launch(int st) {
+    if (st < 0 || st > T_ + 1) return;      // (busy or failed: nothing of the chain was touched / an error follows)
+    ++sweepLaunchesRun_; sweepTreesInside_ += st == T_ + 1 ? T_ : st;
+    sweepSpecSteps_ += sweepStatus_[13]; sweepSpecOk_ += sweepStatus_[14];
+  }
   int64_t sweep_busy() const { return sweepBusy_; }
 
   // HIP-event timing of the per-leapfrog O(N) sums (hmc_mode 1 path: e = e0 - X beta - Z b, |e|^2, X'e, Z'e) on the
@@ -3031,6 +3067,7 @@ class DevHip {
   enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_SWEEP = 4, PATH_STREAM = 5 };
   bool sweepOk_ = false, sweepRegsOk_ = false, sweepStreamOk_ = false, sweepSolo_ = false, sweepFew_ = false, sweepStream_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
   int64_t sweepCount_ = 0, sweepHandOvers_ = 0;
+  int64_t sweepLaunchesRun_ = 0, sweepTreesInside_ = 0, sweepSpecSteps_ = 0, sweepSpecOk_ = 0;
   int xbufParity_ = 0; long long dbgSweepNo_ = 0; int sweepGrid_ = 0;
   OffsetArgs pend_; bool pendOffset_ = false, pendSigma_ = false;   // Stan -> BART hand-off calls held for the one-launch form (offset_from_params)
   int pathReq_ = 0, path_ = 0, sharing_ = 1;

@@ -120,6 +120,8 @@ class SamplerCore {
   SamplerCore(const s4b_bart_control* bc, const s4b_bart_data* bd, const s4b_stan_data* sd, const s4b_stan_control* sc,
               const s4b_common_control* cc, const uint32_t* rstate) {
     if (!bc || !bd || !sd || !sc || !cc || !rstate) throw std::invalid_argument("create: NULL argument");
+    // (first thing read of the struct: a caller built against an older, shorter layout is refused before any newer field is touched)
+    if (bc->interface_version != S4B_INTERFACE_VERSION) throw std::invalid_argument("s4b_bart_control.interface_version must be S4B_INTERFACE_VERSION (the caller was compiled against another revision of stan4bart_amd.h)");
     if (bd->n != sd->N) throw std::invalid_argument("bart data n != stan data N");
     if (bd->n < 1 || bd->p < 1) throw std::invalid_argument("bart data must have n >= 1, p >= 1");
     if (bc->n_trees < 1) throw std::invalid_argument("n_trees must be >= 1");
@@ -583,10 +585,10 @@ class SamplerCore {
       if (!ok || !(sc6[0] > 0.0)) throw std::invalid_argument("sampler state: non-finite value, non-positive step size or inverse metric");
     }
     double kState = 0.0;
+    std::memcpy(&kState, &hd.reserved[0], 8);
     if (kModeled_) {
-      std::memcpy(&kState, &hd.reserved[0], 8);
-      if (!(kState > 0.0) || !std::isfinite(kState)) throw std::invalid_argument("sampler state: k must be positive and finite");
-    }
+      if (!(kState > 0.0) || !std::isfinite(kState)) throw std::invalid_argument("sampler state: k must be positive and finite (the state of a sampler with a fixed k carries none)");
+    } else if (kState != 0.0) throw std::invalid_argument("sampler state: it carries the value of a modeled k, this sampler's k is fixed");
     // ---- commit
     if (kModeled_) dev_.set_k(kState);
     nuts_->set_state(ns);

@@ -181,7 +181,7 @@ def teacher_forced(oracle_lib, lib, prefix, args, seed=12345, patch=None, compar
     return np.array(rows).T, window_ends
 
 
-def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True, sharing=None, tree_path=None):
+def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True, sharing=None, tree_path=None, test_hook=None):
     """stan4bart_fit_worker (reference R/stan4bart_fit.R:33-60) with the diagnostics the parity tests compare.
     ``sharing = (before_warmup, before_sampling)``: device-sharing hints given at those two points (None: not given)."""
     import copy
@@ -199,6 +199,8 @@ def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True, sharing
             s.set_device_sharing(sharing[0])
         if tree_path is not None:
             s.set_tree_path(tree_path)
+        if test_hook is not None:
+            s.set_test_hook(*test_hook)
         traces = []
         if args.warmup > 0:
             out["warmup"] = s.run(args.warmup, True, results_type)
@@ -222,6 +224,8 @@ def run_chain(lib, prefix, args, seed=12345, results_type=0, trace=True, sharing
         out["counters"] = s.get_counters()
         out["tree_path"] = s.get_tree_path()
         out["sweep_stats"] = s.get_sweep_stats()
+        out["sweep_busy"] = s.get_sweep_busy()
+        out["sweep_spec"] = s.get_sweep_spec()
         out["fused_stats"] = s.get_fused_stats()
     finally:
         s.free()

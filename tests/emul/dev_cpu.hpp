@@ -257,6 +257,8 @@ class DevCpu {
   void reset_fused_scales() {}
   void sweep_stats(int64_t out[2]) const { out[0] = 0; out[1] = 0; }
   int64_t sweep_busy() const { return 0; }
+  void set_test_hook(int, int64_t) { throw std::invalid_argument("set_test_hook: the emulation of the device layer has no persistent launch"); }
+  void sweep_spec(int64_t out[4]) const { out[0] = 0; out[1] = 0; out[2] = 0; out[3] = 0; }
   void profile_sweep(int nSweeps, int thin, double* out) { for (int i = 0; i < 8; ++i) out[i] = 0.0; for (int k = 0; k < nSweeps; ++k) sweep(thin); }
   void test_fits(double* out) {
     for (size_t i = 0; i < nTest_; ++i) {

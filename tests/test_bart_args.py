@@ -200,8 +200,23 @@ def test_k_hyperprior_state_round_trip_and_teacher_forcing(oracle_lib, emul_lib)
         bad = bytearray(sv.bytes()); bad[32:40] = np.float64(-1.0).tobytes()
         with pytest.raises(RuntimeError, match="k must be positive"):
             s.set_state(bytes(bad))
+        good = sv.bytes()
     finally:
         s.free()
+    # the flag is checked in both directions: the state of a modeled-k chain is refused by a sampler whose k is fixed, and vice versa,
+    # by the product's host logic and by the oracle alike
+    fixed, _ = friedman_case(n=120, ranef=True, warmup=8, iter=20, T=7)
+    for lib, pfx in ((emul_lib, "emu_"), (oracle_lib, "orc_")):
+        f = make_sampler(lib, pfx, fixed)
+        m = make_sampler(lib, pfx, args)
+        try:
+            with pytest.raises(RuntimeError, match="modeled k"):
+                f.set_state(good)
+            with pytest.raises(RuntimeError, match="k must be positive"):
+                m.set_state(f.get_state())
+            f.set_state(f.get_state()); m.set_state(good)
+        finally:
+            f.free(); m.free()
 
 
 def test_r_gamma_is_a_gamma_sampler(oracle_lib):

@@ -7,7 +7,7 @@
 import numpy as np
 import pytest
 
-from conftest import assert_chain_parity, c5_case, friedman_case, ihdp_case, make_sampler, run_chain, teacher_forced
+from conftest import StateView, assert_chain_parity, assert_state_parity, c5_case, friedman_case, ihdp_case, make_sampler, run_chain, teacher_forced
 
 pytestmark = pytest.mark.gpu
 
@@ -25,6 +25,56 @@ def test_config3_full_size_both_gradient_modes(oracle_lib, hip_lib):
     assert_chain_parity(a, b1)
     np.testing.assert_allclose(b0["sample"]["stan"], b1["sample"]["stan"], rtol=1e-6, atol=1e-9)
     assert np.array_equal(b0["trace"], b1["trace"])
+
+
+def test_config3_stationary_teacher_forced(oracle_lib, hip_lib):
+    """The regime the benchmark's headline is measured in, under the oracle: BASELINE config 3 at full size (n = 1e6, p = 50,
+    200 trees, random slopes — 255 pass workgroups + the control workgroup, both exchange rings), the HIP chain burned in for 300 warm-up iterations
+    (trees of 4 - 5 leaves, ~98 % of the moves rejected, hundreds of leapfrogs per transition), adaptation disengaged.  Then teacher forcing, as
+    conftest.teacher_forced does it: the state is injected into the oracle, both advance ONE sampling iteration, everything is compared — tree-move
+    trace, generator state, NUTS depth / leapfrogs / divergence bit-exact, floats to 1e-6, the whole state after the iteration —, the oracle's state
+    goes back into the HIP sampler, and again; each iteration once per gradient mode on the HIP side.  And the sweeps ran where the headline runs:
+    one persistent launch per sweep, none handed over, at least 80 % of the tree updates publishing their statistics before the verdict."""
+    burn = 300
+    args, _ = friedman_case(n=1_000_000, p=50, T=200, warmup=burn, iter=burn + 4, slopes=True, keep_fits=False)
+    sp = make_sampler(hip_lib, "s4b_", args)
+    so = make_sampler(oracle_lib, "orc_", args)
+    try:
+        sp.run(burn, True, 0)
+        sp.disengage_adaptation()
+        so.disengage_adaptation()
+        assert sp.get_tree_path()[1] == "persistent"
+        spec0, stats0 = sp.get_sweep_spec(), sp.get_sweep_stats()
+        assert stats0 == (burn + 1, 0), stats0
+        st = sp.get_state()
+        so.set_trace(True); sp.set_trace(True)
+        launches = 0
+        for it in range(2):
+            so.set_state(st)
+            ro = so.run(1, False, 0)
+            to = so.get_trace()
+            after = StateView(so.get_state())
+            for mode in (0, 1):
+                sp.set_state(st)
+                sp.set_hmc_mode(mode)
+                rp = sp.run(1, False, 0)
+                launches += 1
+                ctx = f"stationary iteration {it}, hmc_mode {mode}"
+                assert np.array_equal(to, sp.get_trace()), ctx + ": tree-move trace differs"
+                assert np.array_equal(ro["stan"][3:6], rp["stan"][3:6]), ctx + f": NUTS depth / n_leapfrog / divergent differ: {ro['stan'][3:6].ravel()} vs {rp['stan'][3:6].ravel()}"
+                np.testing.assert_allclose(ro["stan"], rp["stan"], rtol=1e-6, atol=1e-9, err_msg=ctx)
+                np.testing.assert_allclose(ro["bart"]["train"], rp["bart"]["train"], rtol=1e-6, atol=1e-9, err_msg=ctx)
+                assert np.array_equal(ro["bart"]["varcount"], rp["bart"]["varcount"]), ctx
+                assert_state_parity(after, StateView(sp.get_state()))
+            assert ro["stan"][4, 0] >= 63, f"not the stationary regime: {ro['stan'][4, 0]} leapfrogs in the transition"
+            st = so.get_state()
+        spec1, stats1 = sp.get_sweep_spec(), sp.get_sweep_stats()
+        assert stats1 == (burn + 1 + launches, 0), stats1
+        ran, inside, early, ok = (b - a for a, b in zip(spec0, spec1))
+        assert ran == launches and inside == launches * 200
+        assert early >= 0.8 * inside and ok >= 0.9 * early, (ran, inside, early, ok)
+    finally:
+        so.free(); sp.free()
 
 
 def test_config4_ihdp_shape_probit(oracle_lib, hip_lib):

@@ -100,6 +100,25 @@ def test_error_reporting(emul_lib):
         run_chain(emul_lib, "emu_", args)
 
 
+def test_interface_version_is_checked_at_create(emul_lib, oracle_lib):
+    """s4b_bart_control and s4b_results have grown fields over the revisions and carry no size field: create() refuses a caller whose header is not
+    this one's (the word was `reserved`, 0, in the older headers) before it reads any newer field."""
+    from stan4bart_amd import abi
+    hdr = open(os.path.join(ROOT, "include", "stan4bart_amd.h")).read()
+    assert int(re.search(r"#define S4B_INTERFACE_VERSION (\d+)", hdr).group(1)) == abi.INTERFACE_VERSION
+    args, _ = friedman_case()
+    saved = abi.INTERFACE_VERSION
+    try:
+        for v in (0, saved - 1, saved + 1):
+            abi.INTERFACE_VERSION = v
+            for lib, pfx in ((emul_lib, "emu_"), (oracle_lib, "orc_")):
+                with pytest.raises(RuntimeError, match="interface_version"):
+                    run_chain(lib, pfx, args)
+    finally:
+        abi.INTERFACE_VERSION = saved
+    run_chain(emul_lib, "emu_", args)
+
+
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "stan4bart_amd.h")).read()
     return sorted(set(re.findall(r"S4B_FN\((\w+)\)\s*\(", hdr)) - {"name"})

@@ -14,8 +14,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "stan4bart_amd", "csrc")
-MAX_SPILLED_VGPRS = 16       # product build of round 5: 14 (13 before image 0 was drawn a step ahead; a second inlined copy of the drawing code: 20)
-MAX_SCRATCH_BYTES = 1960     # product build of round 5: 1896 bytes per lane (the hand-over tail's global-memory control step, not the step loops)
+MAX_SPILLED_VGPRS = 2        # product build since round 5: 0 (round 4: 14, worth 3 - 6 % of the sweep; a second inlined copy of the drawing code: 20)
+MAX_SCRATCH_BYTES = 1880     # product build since round 5: 1848 bytes per lane (the hand-over tail's global-memory control step, not the step loops)
 
 
 def _usage(extra=()):
@@ -46,10 +46,10 @@ def test_k_sweep_register_allocation_is_the_one_that_was_measured():
     u = both["k_sweep"]
     assert u["vgprs"] <= 256 and u["occupancy"] >= 2, u          # eight waves of one workgroup must fit a CU
     assert u["spill"] <= MAX_SPILLED_VGPRS, f"k_sweep now spills {u['spill']} VGPRs (measured build: 0 since round 5, 14 in round 4; 21-24 cost 6 % of the benchmark): {u}"
-    assert u["scratch"] <= MAX_SCRATCH_BYTES, f"k_sweep's scratch grew to {u['scratch']} bytes per lane (measured build: 1896): {u}"
+    assert u["scratch"] <= MAX_SCRATCH_BYTES, f"k_sweep's scratch grew to {u['scratch']} bytes per lane (measured build: 1848): {u}"
     # the streaming variant (n > 1.04e6): its pass keeps two batches of observations in flight per thread — no spill inside that loop
     v = both["k_sweep_stream"]
-    assert v["vgprs"] <= 256 and v["occupancy"] >= 2 and v["spill"] <= 16 and v["scratch"] <= MAX_SCRATCH_BYTES, v      # (round 5: 0)
+    assert v["vgprs"] <= 256 and v["occupancy"] >= 2 and v["spill"] <= MAX_SPILLED_VGPRS and v["scratch"] <= MAX_SCRATCH_BYTES, v      # (round 5: 0)
     # the launch for few observations per thread (same body, statistics with the missing quads left out)
     w = both["k_sweep_few"]
     assert w["vgprs"] <= 256 and w["occupancy"] >= 2 and w["spill"] <= MAX_SPILLED_VGPRS and w["scratch"] <= MAX_SCRATCH_BYTES, w

@@ -6,36 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from conftest import assert_chain_parity, run_chain
-from stan4bart_amd import GroupTerm, make_sampler_args
+from large_cases import large_case
 from stan4bart_amd._lib import load_library
-
-
-def large_case(seed):
-    g = np.random.default_rng(500000 + seed)
-    n = int(g.choice([g.integers(50000, 200000), g.integers(200000, 700000), g.integers(700000, 1044000)]))
-    p = int(g.integers(1, 9))
-    cols = [(g.random(n) < 0.3).astype(np.float64) if g.random() < 0.25 else (g.normal(size=n) if g.random() < 0.5 else g.random(n)) for _ in range(p)]
-    xb = np.column_stack(cols)
-    x4 = g.random(n)
-    f = 3.0 * np.sin(2.0 * xb[:, 0]) + (xb[:, -1] > np.median(xb[:, -1])) * 2.0 + 1.5 * x4
-    binary = bool(g.random() < 0.15) and n < 150000              # (probit latents are serial: keep those cases small)
-    yc = f + g.normal(size=n) * g.choice([0.1, 1.0, 3.0])
-    y = (yc > np.median(yc)).astype(np.float64) if binary else yc * g.choice([1.0, 1e-3, 250.0])
-    bart_args = {"n.trees": int(g.integers(1, 13)), "n.cuts": int(g.choice([1, 5, 100])), "k": float(g.choice([0.5, 2.0, 4.0]))}
-    r = g.random()
-    if r < 0.3:
-        bart_args.update(base=0.99, power=0.5)
-    elif r < 0.45:
-        bart_args.update(base=0.99, power=0.3, k=0.3)             # trees of tens of leaves from the prior: hand-overs
-    if g.random() < 0.2:
-        bart_args["useQuantiles"] = True
-    warmup = int(g.integers(1, 5)); it = warmup + int(g.integers(2, 8))
-    groups = [GroupTerm(g.integers(1, 6, size=n), None, "g.1")] if g.random() < 0.4 else []
-    args = make_sampler_args(y, xb, X=x4[:, None], groups=groups, family="binomial" if binary else "gaussian", iter=it, warmup=warmup, bart_args=bart_args,
-                             x_test=xb[:50].copy() if g.random() < 0.3 else None)
-    if bart_args.get("power") == 0.3:
-        args.node_capacity = 1024
-    return args, dict(n=n, p=p, binary=binary, **bart_args)
 
 
 if __name__ == "__main__":

@@ -7,20 +7,22 @@
 #      profiles/pmc_traffic.json (HBM bytes per launch of the tree-update kernel: k_sweep at n = 1e6 — one launch per sweep —, k_tree<true> at n = 1e7; gfx950 correction of MI355X_MICROARCH.md)
 # Counter passes are separate runs without any tracing option, and the program after `--` is python3 itself.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
+BURN=${2:-1000}      # burn-in of the n = 1e6 chain (the benchmark's default); n = 1e7 burns in for BURN7
+BURN7=${3:-300}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT" "$ROOT/profiles"
 cd /tmp && export TMPDIR=/tmp
 newest_db() { find "$1" -name '*_results.db' -printf '%T@ %p\n' 2>/dev/null | sort -n | tail -1 | cut -d' ' -f2-; }
-TRAFFIC="{\"_note\": \"$TAG: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python3 bench.py --n N --steps 2 --warmup 1 --profile-sweeps 1, summarised by tools/pmc_traffic.py; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)\""
+TRAFFIC="{\"_note\": \"$TAG: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python3 bench.py --n N --burn-in $BURN (n = 1e6) / $BURN7 (n = 1e7) --steps 2 --warmup 1 --profile-sweeps 1: the chain past its burn-in, like the headline, summarised by tools/pmc_traffic.py; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)\""
 for N in 1000000 10000000; do
-  # (the kernel trace at n = 1e6 is taken from the benchmark's own chain — its default 1000 warm-up iterations first: a cold chain accepts more moves, a stationary one carries more bins per step;
-  # the counter passes and n = 1e7 use a short burn-in)
-  COMMON="--n $N --no-cpu-baseline --no-extra-configs --no-hmc-mode1 --target-n 0 --mode-iters 0 --burn-in 30"
-  TRACEBURN=30; [ "$N" = "1000000" ] && TRACEBURN=1000
+  # (every pass — kernel trace AND counters — runs the chain the benchmark times: past its burn-in.  A cold chain accepts more moves, a stationary one
+  # carries more bins per step: until round 5 the counter passes and n = 1e7 used a 30-iteration burn-in)
+  TRACEBURN=$BURN7; [ "$N" = "1000000" ] && TRACEBURN=$BURN
+  COMMON="--n $N --no-cpu-baseline --no-extra-configs --no-hmc-mode1 --target-n 0 --mode-iters 0 --burn-in $TRACEBURN"
   rm -rf "$OUT/prof_n$N" "$OUT/pmc_fetch_n$N" "$OUT/pmc_write_n$N"
-  timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_n$N" -- python3 "$ROOT/bench.py" $COMMON --burn-in $TRACEBURN --steps 20 --warmup 5 > "$OUT/bench_prof_n$N.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_n$N" -- python3 "$ROOT/bench.py" $COMMON --steps 20 --warmup 5 > "$OUT/bench_prof_n$N.log" 2>&1
   python3 "$ROOT/tools/rocpd_summary.py" "$(newest_db "$OUT/prof_n$N")" "$ROOT/profiles/${TAG}_rocprofv3_prof_n$N.txt"
   timeout 600 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch_n$N" -- python3 "$ROOT/bench.py" $COMMON --steps 2 --warmup 1 --profile-sweeps 1 > "$OUT/pmc_fetch_n$N.log" 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write_n$N" -- python3 "$ROOT/bench.py" $COMMON --steps 2 --warmup 1 --profile-sweeps 1 > "$OUT/pmc_write_n$N.log" 2>&1
