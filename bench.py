@@ -359,7 +359,7 @@ def main():
     ap.add_argument("--tree-path", default="auto", choices=["auto", "two-kernel", "fused", "persistent", "stream"])
     ap.add_argument("--c5-n", type=int, default=10_000_000, help="observations of the BASELINE config 5 leg of extra_configs (0 = skip; N = 1 only)")
     ap.add_argument("--target-burn-in", type=int, default=300, help="warm-up iterations of the n = --target-n leg before its sweeps are profiled")
-    ap.add_argument("--c5-burn-in", type=int, default=300, help="warm-up iterations of the config 5 leg before its 20 timed sampling iterations")
+    ap.add_argument("--c5-burn-in", type=int, default=1000, help="warm-up iterations of the config 5 leg before its 20 timed sampling iterations")
     ap.add_argument("--target-n", type=int, default=10_000_000,
                     help="also measure the sweep kernel at north_star's roofline-target size (0 = skip; N = 1 only)")
     ap.add_argument("--emul", action="store_true",
