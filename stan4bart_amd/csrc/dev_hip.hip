@@ -2700,6 +2700,33 @@ class DevHip {
       { double a8 = 0, a9 = 0, a11 = 0; int c8 = 0;
         for (int b = 0; b < 255; ++b) if (w[b * 16 + 1]) { const double kq = 1.0 / (100.0 * (double)w[b * 16 + 1]); a8 += (double)w[b * 16 + 8] * kq; a9 += (double)w[b * 16 + 9] * kq; a11 += (double)w[b * 16 + 11] * kq; ++c8; }
         if (c8) fprintf(stderr, "SWEEP per workgroup (mean over the workgroups), us after the totals were seen, steps that speculate: wave 3's leaf values out %.2f, wave 5 starts the statistics %.2f, wave 4 has published (below), wave 5 through with the step (steps borne out, per speculating step) %.2f\n", a8 / c8, a9 / c8, a11 / c8); }
+      { static unsigned long long wd[256 * 64]; sweep_wd_fetch(wd);
+        double d[8], c[8], big[8], mx[8]; for (int k = 0; k < 8; ++k) { d[k] = 0; c[k] = 0; big[k] = 0; mx[k] = 0; }
+        for (int b = 0; b < 255; ++b) for (int k = 0; k < 8; ++k) { d[k] += (double)wd[b * 64 + k]; c[k] += (double)wd[b * 64 + 8 + k]; big[k] += (double)wd[b * 64 + 16 + k]; mx[k] = std::max(mx[k], (double)wd[b * 64 + 24 + k] / 100.0); }
+        auto A = [&](int k) { return c[k] > 0 ? d[k] / (100.0 * c[k]) : 0.0; };
+        fprintf(stderr, "SWEEP pass wave 5, durations (mean over workgroups and steps; counts %.0f / %.0f / %.0f), us: end of the previous step -> next tree's leaf ids requested %.2f, wait for the image drawn ahead %.2f, routing under it %.2f, "
+                        "wait for wave 3's leaf values %.2f, ahead pass %.2f, wait for the verdict + fold %.2f | a step done the old way with its ahead pass behind it %.2f | wave 3's wait for the ahead pass of the step before %.2f\n",
+                c[1], c[4], c[6], A(0), A(1), A(2), A(3), A(4), A(5), A(6), A(7));
+        { // the workgroups whose wave 3 waits longest for its pass waves: their own phase means
+          int worst[3] = {-1, -1, -1}; double wv[3] = {-1, -1, -1};
+          for (int b = 0; b < 255; ++b) { const double v = wd[b * 64 + 8 + 7] ? (double)wd[b * 64 + 7] / (double)wd[b * 64 + 8 + 7] : 0.0;
+            for (int q = 0; q < 3; ++q) if (v > wv[q]) { for (int r = 2; r > q; --r) { wv[r] = wv[r - 1]; worst[r] = worst[r - 1]; } wv[q] = v; worst[q] = b; break; } }
+          for (int q = 0; q < 3; ++q) if (worst[q] >= 0) { const int b = worst[q]; fprintf(stderr, "SWEEP workgroup %d (wave 3 waits longest for its pass waves), its own means of the eight phases:", b);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %.2f", wd[b * 64 + 8 + k] ? (double)wd[b * 64 + k] / (100.0 * (double)wd[b * 64 + 8 + k]) : 0.0); fprintf(stderr, "\n"); }
+          double lo = 1e9, hi = 0; int blo = -1, bhi = -1;
+          for (int b = 0; b < 255; ++b) { const double v = wd[b * 64 + 8 + 4] ? (double)wd[b * 64 + 4] / (100.0 * (double)wd[b * 64 + 8 + 4]) : 0.0; if (v < lo) { lo = v; blo = b; } if (v > hi) { hi = v; bhi = b; } }
+          fprintf(stderr, "SWEEP ahead pass, per-workgroup means: %.2f (workgroup %d) .. %.2f us (workgroup %d)\n", lo, blo, hi, bhi);
+          lo = 1e9; hi = 0;
+          for (int b = 0; b < 255; ++b) { const double v = wd[b * 64 + 8 + 2] ? (double)wd[b * 64 + 2] / (100.0 * (double)wd[b * 64 + 8 + 2]) : 0.0; if (v < lo) { lo = v; blo = b; } if (v > hi) { hi = v; bhi = b; } }
+          fprintf(stderr, "SWEEP routing, per-workgroup means: %.2f (workgroup %d) .. %.2f us (workgroup %d)\n", lo, blo, hi, bhi); }
+        { double as[8], ac[8]; for (int k = 0; k < 8; ++k) { as[k] = 0; ac[k] = 0; }
+          for (int b = 0; b < 255; ++b) for (int k = 0; k < 8; ++k) { as[k] += (double)(long long)wd[b * 64 + 32 + k]; ac[k] += (double)wd[b * 64 + 48 + k]; }
+          auto M = [&](int k) { return ac[k] > 0 ? as[k] / (100.0 * ac[k]) : 0.0; };
+          fprintf(stderr, "SWEEP moments of a step, us after this workgroup saw its totals (means over workgroups and steps): decider past the totals %.2f, has wave 3's leaf values %.2f, past its wait for the pass waves %.2f, verdict out %.2f, "
+                          "decider's step ends %.2f | proposal settled %.2f, wave 1 starts drawing the ahead image %.2f, has drawn it %.2f\n", M(0), M(1), M(2), M(3), M(4), M(7), M(5), M(6)); }
+        fprintf(stderr, "SWEEP the same phases: share of the steps in which the phase took more than 3 us (maximum, us):");
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " [%d] %.4f (%.1f)", k, c[k] > 0 ? big[k] / c[k] : 0.0, mx[k]);
+        fprintf(stderr, "\n"); }
       fprintf(stderr, "SWEEP per workgroup: totals seen -> speculative statistics published, us: min %.2f mean %.2f max %.2f (workgroup %d) over %d workgroups; the moment the totals are seen, relative to the mean: %.2f (workgroup %d) .. %.2f us (workgroup %d)\n",
               mn, cntW ? sm / cntW : 0.0, mx, argmx, cntW, smn, argsmn, smx, argsmx); }
 #endif

@@ -13,6 +13,7 @@
 #   tl           the instrumented timeline (make sweeptiming build)              -> timeline.txt
 #   profile      tools/profile_round.sh <tag>
 #   large A B    tools/fuzz_large.py A B
+#   libs L1 L2 .. --   step_probe --iters 300 once per variant library
 set -u
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p "$O"
@@ -31,6 +32,11 @@ while [ $# -gt 0 ]; do
           S4B_LIB_PATH=$PWD/stan4bart_amd/csrc/$lib timeout 600 python tools/step_probe.py --iters 300 --sweeps 5 > "$O/ab_other_$r.json" 2> "$O/ab_other_$r.err"
         done
         for f in "$O"/ab_*.json; do echo "$f $(cut -c1-400 "$f")"; done ;;
+    libs) # probe a list of variant libraries once each:  libs libs4b_p1.so libs4b_p2.so --
+        while [ $# -gt 0 ] && [ "$1" != "--" ]; do lib=$1; shift
+          S4B_LIB_PATH=$PWD/stan4bart_amd/csrc/$lib timeout 600 python tools/step_probe.py --iters 300 --sweeps 5 > "$O/probe_$lib.json" 2> "$O/probe_$lib.err"
+          echo "$lib $(cut -c1-60 "$O/probe_$lib.json") $(grep -o '"per_tree_wall_us": [0-9.]*' "$O/probe_$lib.json")"; done
+        [ $# -gt 0 ] && shift ;;
     wgt) S4B_LIB_PATH=$PWD/stan4bart_amd/csrc/libs4b_wgt.so timeout 600 python tools/step_probe.py --iters 300 --sweeps 5 > "$O/wgt.json" 2> "$O/wgt.txt"; cat "$O/wgt.txt" ;;
     tl) S4B_LIB_PATH=$PWD/stan4bart_amd/csrc/libs4b_sweeptiming.so timeout 600 python tools/step_probe.py --iters 300 --sweeps 5 > "$O/timeline.json" 2> "$O/timeline.txt"; cat "$O/timeline.txt" ;;
     profile) bash tools/profile_round.sh "$TAG" ;;

@@ -39,7 +39,10 @@ def main():
     s = Sampler(load_library(), "s4b_", args, rng.state)
     s.set_tree_path(a.path)
     s.run(a.iters, True, 0)
+    spec0 = s.get_sweep_spec()
     prof = s.profile_sweep(a.sweeps)
+    spec1 = s.get_sweep_spec()
+    prof["sweep_spec_profiled"] = dict(zip(("launches", "tree_updates", "published_before_verdict", "borne_out"), (b - c for b, c in zip(spec1, spec0))))
     s.free()
     prof["per_tree_wall_us"] = prof["sweep_wall_us"] / a.trees
     prof["GBs_per_tree_wall"] = 22.0 * a.n / (prof["per_tree_wall_us"] * 1e-6) / 1e9
