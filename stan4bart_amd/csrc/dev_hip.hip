@@ -2653,7 +2653,7 @@ class DevHip {
   void profile_sweep_persistent(int nSweeps, int thin, double* out) {
     double sum = 0; int cnt = 0;
 #ifdef S4B_SWEEP_WG
-    { sync(); static unsigned long long dropW[256 * 16]; sweep_wg_fetch(dropW); }
+    { sync(); static unsigned long long dropW[256 * 16]; sweep_wg_fetch(dropW); static unsigned long long dropD[256 * 64]; sweep_wd_fetch(dropD); }
 #endif
 #ifdef S4B_SWEEP_TIMING
     { sync(); unsigned long long drop[128]; sweep_timing_fetch(drop); }     // (only the sweeps profiled here: not the chain's first ones, which rebuild every structure cache)

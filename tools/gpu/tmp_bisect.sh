@@ -1,0 +1,3 @@
+for r in 1 2 3 4 5 6; do
+  timeout 600 python -m pytest tests/test_gpu_configs.py -m gpu -x -q -k "config3_full_size" --timeout 300 2>&1 | tail -1 | sed "s/^/run $r: /"
+done
