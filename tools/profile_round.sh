@@ -38,3 +38,5 @@ timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_fused" -- python3 "$R
 python3 "$ROOT/tools/rocpd_summary.py" "$(newest_db "$OUT/prof_fused")" "$ROOT/profiles/${TAG}_rocprofv3_prof_fused_n1000000.txt"
 # the box's repository copy is scratch: hand the summaries back through gpurun_out/
 mkdir -p "$OUT/profiles" && cp "$ROOT"/profiles/${TAG}_rocprofv3_* "$ROOT/profiles/pmc_traffic.json" "$OUT/profiles/"
+# (the raw rocprofv3 databases stay on the box: gpurun hands back at most 64 MiB)
+rm -rf "$OUT"/prof_n* "$OUT"/pmc_fetch_n* "$OUT"/pmc_write_n* "$OUT/prof_fused"
