@@ -2700,6 +2700,7 @@ class DevHip {
       { double a8 = 0, a9 = 0, a11 = 0; int c8 = 0;
         for (int b = 0; b < 255; ++b) if (w[b * 16 + 1]) { const double kq = 1.0 / (100.0 * (double)w[b * 16 + 1]); a8 += (double)w[b * 16 + 8] * kq; a9 += (double)w[b * 16 + 9] * kq; a11 += (double)w[b * 16 + 11] * kq; ++c8; }
         if (c8) fprintf(stderr, "SWEEP per workgroup (mean over the workgroups), us after the totals were seen, steps that speculate: wave 3's leaf values out %.2f, wave 5 starts the statistics %.2f, wave 4 has published (below), wave 5 through with the step (steps borne out, per speculating step) %.2f\n", a8 / c8, a9 / c8, a11 / c8); }
+#ifdef S4B_SWEEP_WGD
       { static unsigned long long wd[256 * 64]; sweep_wd_fetch(wd);
         double d[8], c[8], big[8], mx[8]; for (int k = 0; k < 8; ++k) { d[k] = 0; c[k] = 0; big[k] = 0; mx[k] = 0; }
         for (int b = 0; b < 255; ++b) for (int k = 0; k < 8; ++k) { d[k] += (double)wd[b * 64 + k]; c[k] += (double)wd[b * 64 + 8 + k]; big[k] += (double)wd[b * 64 + 16 + k]; mx[k] = std::max(mx[k], (double)wd[b * 64 + 24 + k] / 100.0); }
@@ -2727,6 +2728,7 @@ class DevHip {
         fprintf(stderr, "SWEEP the same phases: share of the steps in which the phase took more than 3 us (maximum, us):");
         for (int k = 0; k < 8; ++k) fprintf(stderr, " [%d] %.4f (%.1f)", k, c[k] > 0 ? big[k] / c[k] : 0.0, mx[k]);
         fprintf(stderr, "\n"); }
+#endif
       fprintf(stderr, "SWEEP per workgroup: totals seen -> speculative statistics published, us: min %.2f mean %.2f max %.2f (workgroup %d) over %d workgroups; the moment the totals are seen, relative to the mean: %.2f (workgroup %d) .. %.2f us (workgroup %d)\n",
               mn, cntW ? sm / cntW : 0.0, mx, argmx, cntW, smn, argsmn, smx, argsmx); }
 #endif
