@@ -2990,7 +2990,7 @@ class DevHip {
   void sweep_spec(int64_t out[4]) const { out[0] = sweepLaunchesRun_; out[1] = sweepTreesInside_; out[2] = sweepSpecSteps_; out[3] = sweepSpecOk_; }
   void count_persistent_launch(int st) {
     if (st < 0 || st > T_ + 1) return;      // (busy or failed: nothing of the chain was touched / an error follows)
-    ++sweepLaunchesRun_; sweepTreesInside_ += st == T_ + 1 ? T_ : st;
+    ++sweepLaunchesRun_; sweepTreesInside_ += st == T_ + 1 ? T_ : std::max(st - 1, 0);      // (status t <= T: steps 0 .. t-1 ran inside, i.e. trees 0 .. t-2 were decided there)
     sweepSpecSteps_ += sweepStatus_[13]; sweepSpecOk_ += sweepStatus_[14];
   }
   int64_t sweep_busy() const { return sweepBusy_; }
