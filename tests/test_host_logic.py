@@ -119,6 +119,20 @@ def test_interface_version_is_checked_at_create(emul_lib, oracle_lib):
     run_chain(emul_lib, "emu_", args)
 
 
+def test_round6_extensions_on_the_emulated_device_layer(emul_lib):
+    """s4b_get_sweep_spec reports zeros where no persistent launch exists, and the busy test hook is refused there (include/stan4bart_amd.h)."""
+    from conftest import make_sampler
+    args, _ = friedman_case()
+    s = make_sampler(emul_lib, "emu_", args)
+    try:
+        s.run(2, True)
+        assert s.get_sweep_spec() == (0, 0, 0, 0) and s.get_sweep_stats() == (0, 0) and s.get_sweep_busy() == 0
+        with pytest.raises(RuntimeError, match="set_test_hook"):
+            s.set_test_hook(1, 2)
+    finally:
+        s.free()
+
+
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "stan4bart_amd.h")).read()
     return sorted(set(re.findall(r"S4B_FN\((\w+)\)\s*\(", hdr)) - {"name"})
