@@ -506,19 +506,126 @@ __device__ __forceinline__ void leaf_stats_draws(const WaveTables& tb, const Wav
 }
 
 // Model view of the control wave: the prior tables sit in registers (lane d / lane k), LDS only beyond 64 / 128
-struct WaveModel : ModelView {
+// (SPL: cgm(split.probs) — the weighted predictor choice — on the wave-register path: only the persistent sweep's kernels k_sweep_sp /
+// k_sweep_few_sp are compiled with it; everywhere else the wave-register code is compiled without and such samplers take the
+// pointer-storage control code)
+template <bool SPL>
+struct WaveModelT : ModelView {
   WaveArrD pg, lpg, l1pg, li0, li1; int nc0, nc1;
 };
-__device__ __forceinline__ double mv_pg_depth(const WaveModel& m, int d) { return d < 64 ? m.pg.get(d) : S4B_UNI(m.pgDepth[d]); }
-__device__ __forceinline__ double mv_log_pg(const WaveModel& m, int d) { return d < 64 ? m.lpg.get(d) : S4B_UNI(m.logPg[d]); }
-__device__ __forceinline__ double mv_log1m_pg(const WaveModel& m, int d) { return d < 64 ? m.l1pg.get(d) : S4B_UNI(m.log1mPg[d]); }
-__device__ __forceinline__ double mv_log_int(const WaveModel& m, int k) {
+// (with the weights: spTab, on chip — [0, 128) the running sum of the weights through predictor v over the predictors that have cuts, in predictor order;
+// [128, 256) log(weight of predictor v); [256] the sum over all of them, [257] its logarithm: what the sums below come to at a node where every predictor
+// is still available, which is nearly every node — k_sweep_sp's prologue fills it)
+template <>
+struct WaveModelT<true> : ModelView {
+  WaveArrD pg, lpg, l1pg, li0, li1; int nc0, nc1; const double* spTab;
+};
+constexpr int SP_TAB = 258;
+typedef WaveModelT<false> WaveModel;
+template <bool SPL> __device__ __forceinline__ double mv_pg_depth(const WaveModelT<SPL>& m, int d) { return d < 64 ? m.pg.get(d) : S4B_UNI(m.pgDepth[d]); }
+template <bool SPL> __device__ __forceinline__ double mv_log_pg(const WaveModelT<SPL>& m, int d) { return d < 64 ? m.lpg.get(d) : S4B_UNI(m.logPg[d]); }
+template <bool SPL> __device__ __forceinline__ double mv_log1m_pg(const WaveModelT<SPL>& m, int d) { return d < 64 ? m.l1pg.get(d) : S4B_UNI(m.log1mPg[d]); }
+template <bool SPL> __device__ __forceinline__ double mv_log_int(const WaveModelT<SPL>& m, int k) {
   return k < 64 ? m.li0.get(k) : (k < 128 ? m.li1.get(k - 64) : S4B_UNI(m.logInt[k]));
 }
-// (the wave-register control path has no weighted predictor choice: samplers with cgm(split.probs) take the pointer-storage path)
-__device__ __forceinline__ const double* mv_split_probs(const WaveModel&) { return nullptr; }
-__device__ __forceinline__ int mv_num_cuts(const WaveModel& m, int v) {
+template <bool SPL> __device__ __forceinline__ const double* mv_split_probs(const WaveModelT<SPL>& m) { return SPL ? m.splitProbs : nullptr; }
+template <bool SPL> __device__ __forceinline__ int mv_num_cuts(const WaveModelT<SPL>& m, int v) {
   return v < 64 ? __builtin_amdgcn_readlane(m.nc0, v) : (v < 128 ? __builtin_amdgcn_readlane(m.nc1, v - 64) : S4B_UNI(m.numCuts[v]));
+}
+
+// cgm(split.probs) on the wave-register path.  Which predictors still have a free cut at node n: lane l answers for predictor 64 chunk + l — the walk up
+// the ancestors is uniform (register reads), every lane narrows the interval of ITS predictor (tv_interval for 64 predictors at once).  The sums over the
+// available predictors are then formed in increasing predictor order, one add per available predictor, exactly as the sequential tv_avail_prob_sum and
+// tv_draw_var of tree_hd.hpp form them: the same doubles, the same draw.  (The sequential versions walk the ancestors once per predictor through register
+// reads: 59 us per tree update at P = 49 against 8 without the weights; these: see DESIGN.md 8.)
+__device__ __forceinline__ unsigned long long wave_avail_mask(const WaveTree& t, const WaveModelT<true>& m, int n, int chunk) {
+  const int v = chunk * 64 + (int)(threadIdx.x & 63);
+  const int ncv = chunk == 0 ? m.nc0 : (chunk == 1 ? m.nc1 : (v < m.P ? m.numCuts[v] : 0));
+  int lo = 0, hi = ncv - 1;
+  int child = n;
+  for (int a = t.parent.get(n); a >= 0; child = a, a = t.parent.get(a)) {
+    const int av = t.var.get(a), s = (int)t.cut.get(a);
+    const bool isLeft = child == t.left.get(a);
+    const bool hit = av == v;
+    hi = (hit && isLeft && s - 1 < hi) ? s - 1 : hi;
+    lo = (hit && !isLeft && s + 1 > lo) ? s + 1 : lo;
+  }
+  return __ballot(v < m.P && ncv > 0 && lo <= hi);
+}
+__device__ __forceinline__ double wave_lane_double(double x, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ double tv_avail_prob_sum(const WaveTree& t, const WaveModelT<true>& m, int n, const double* sp) {
+  if ((int)t.na.get(n) == m.Pvalid) return S4B_UNI(m.spTab[256]);      // nothing exhausted on the way down to n: the sum over all, formed once
+  double tot = 0.0;
+  for (int c = 0; c * 64 < m.P; ++c) {
+    unsigned long long mask = wave_avail_mask(t, m, n, c);
+    const int v = c * 64 + (int)(threadIdx.x & 63);
+    const double mine = v < m.P ? sp[v] : 0.0;
+    while (mask) {
+      const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
+      mask &= mask - 1ull;
+      tot += wave_lane_double(mine, b);
+    }
+  }
+  return tot;
+}
+__device__ __forceinline__ double tv_log_var_prob(const WaveTree& t, const WaveModelT<true>& m, int n, int v, int na) {
+  const double* sp = m.splitProbs;
+  if (!sp) return -mv_log_int(m, na);
+  const double lv = v < 128 ? S4B_UNI(m.spTab[128 + v]) : log(S4B_UNI(sp[v]));
+  if (na == m.Pvalid) return lv - S4B_UNI(m.spTab[257]);
+  return lv - log(tv_avail_prob_sum(t, m, n, sp));
+}
+// (k_sweep_sp's prologue, one wave: the table of the weights)
+__device__ __forceinline__ void wave_fill_sp_tab(const BartArrays& a, double* spTab, int lane) {
+  const double* sp = a.model.splitProbs;
+  double run = 0.0;
+  for (int c = 0; c * 64 < a.P; ++c) {
+    const int v = c * 64 + lane;
+    const bool ok = v < a.P && a.numCuts[v] > 0;
+    const double mine = v < a.P ? sp[v] : 1.0;
+    unsigned long long mask = __ballot(ok);
+    double pre = run;
+    while (mask) {
+      const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
+      mask &= mask - 1ull;
+      run += wave_lane_double(mine, b);
+      pre = lane >= b ? run : pre;
+    }
+    if (c < 2) { spTab[v] = pre; spTab[128 + v] = log(mine); }
+  }
+  if (lane == 0) { spTab[256] = run; spTab[257] = log(run); }
+}
+template <class RNG>
+__device__ __forceinline__ int tv_draw_var(const WaveTree& t, const WaveModelT<true>& m, int n, RNG* rng) {
+  const double* sp = m.splitProbs;
+  if (!sp) { const int good = tv_num_avail(t, m, n); const int idx = r_unif_int(rng, 0, good); return tv_nth_avail_var(t, m, n, idx); }
+  const double u = r_unif(rng) * tv_avail_prob_sum(t, m, n, sp);
+  if ((int)t.na.get(n) == m.Pvalid && m.P <= 128) {
+    // every predictor with cuts is available: the running sums are the table's — the first one beyond u, else the last predictor with cuts
+    const int l = (int)(threadIdx.x & 63);
+    const bool ok0 = l < m.P && m.nc0 > 0, ok1 = 64 + l < m.P && m.nc1 > 0;
+    const unsigned long long v0 = __ballot(ok0), v1 = __ballot(ok1);
+    const unsigned long long h0 = __ballot(ok0 && m.spTab[l] > u), h1 = __ballot(ok1 && m.spTab[64 + l] > u);
+    if (h0) return __builtin_amdgcn_readfirstlane(__ffsll((long long)h0) - 1);
+    if (h1) return __builtin_amdgcn_readfirstlane(64 + __ffsll((long long)h1) - 1);
+    if (v1) return __builtin_amdgcn_readfirstlane(127 - __clzll((long long)v1));
+    return v0 ? __builtin_amdgcn_readfirstlane(63 - __clzll((long long)v0)) : -1;
+  }
+  double run = 0.0; int last = -1;
+  for (int c = 0; c * 64 < m.P; ++c) {
+    unsigned long long mask = wave_avail_mask(t, m, n, c);
+    const int v = c * 64 + (int)(threadIdx.x & 63);
+    const double mine = v < m.P ? sp[v] : 0.0;
+    while (mask) {
+      const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
+      mask &= mask - 1ull;
+      run += wave_lane_double(mine, b); last = c * 64 + b;
+      if (__builtin_amdgcn_readfirstlane((int)(run > u))) return last;
+    }
+  }
+  return last;
 }
 
 // Workgroup of 8 waves with fixed roles, tied together by two LDS hand-shakes (no workgroup barrier after start-up):
@@ -2072,8 +2179,11 @@ class DevHip {
       ldsStep_ = step_lds_bytes(nc_, d.weights != nullptr);
       // automatic choice: the fused launch wins while a tree update is latency-bound; at large n the two-kernel path keeps
       // more waves streaming (4 per SIMD instead of 2)
-      // (cgm(split.probs): the weighted predictor choice lives in the pointer-storage control code only — two kernels per tree)
-      fusedOk_ = perThread <= 255 && ldsStep_ + 24 * 1024 <= 160 * 1024 && d.model.splitProbs == nullptr;
+      // (cgm(split.probs): the weighted predictor choice lives in the pointer-storage control code of k_control / k_step's tail and in the persistent sweep's
+      // k_sweep_sp / k_sweep_few_sp; k_step's own wave-register code is compiled without it: no fused path of choice, k_step only finishes handed-over sweeps)
+      const bool stepOk = perThread <= 255 && ldsStep_ + 24 * 1024 <= 160 * 1024;
+      splitProbs_ = d.model.splitProbs != nullptr;
+      fusedOk_ = stepOk && !splitProbs_;
       fusedAuto_ = perThread <= 8 && fusedOk_;
       a.partF = zalloc<double>((size_t)2 * 3 * a.binCap * a.gridF);
       // persistent sweep (dev_sweep.inc): ONE launch per sweep, the residual in registers, every workgroup deciding redundantly.
@@ -2084,9 +2194,9 @@ class DevHip {
         // beyond SW_PF quads per pass thread the residual does not fit the registers.  The STREAMING variant of the same launch (k_sweep_stream:
         // the pass waves read and write the residual per tree, 22 B per observation and tree update like k_tree, everything else as k_sweep)
         // exists for every size but is only taken on request (choose_path); its workgroup counts must fit the 21-bit field of the exchange words
-        const bool common = fusedOk_ && d.weights == nullptr && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount && sweep_lds_bytes() + 40 * 1024 <= 160 * 1024;
+        const bool common = stepOk && d.weights == nullptr && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount && sweep_lds_bytes() + 40 * 1024 <= 160 * 1024;
         sweepRegsOk_ = common && nQuads <= (int64_t)(a.gridF - 1) * SW_PT * SW_PF;
-        sweepStreamOk_ = common && (n_ + a.gridF - 2) / (a.gridF - 1) + 4 * SW_PT < (int64_t)1 << 21;
+        sweepStreamOk_ = common && !splitProbs_ && (n_ + a.gridF - 2) / (a.gridF - 1) + 4 * SW_PT < (int64_t)1 << 21;
         sweepOk_ = sweepRegsOk_ || sweepStreamOk_;
         // at most 4096 observations: ONE workgroup holds them all and does the control duties too (no exchange: dev_sweep.inc "solo")
         sweepSolo_ = nQuads <= (int64_t)SW_PT * SW_PF;
@@ -2103,6 +2213,8 @@ class DevHip {
           HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
           HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
           HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_few), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
+          HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_sp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
+          HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_few_sp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
         }
       }
       choose_path();
@@ -2181,7 +2293,7 @@ class DevHip {
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsTree_));
     }
     if (ldsApply_ > 64 * 1024) HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsApply_));
-    if (fusedOk_ && ldsStep_ > 32 * 1024) {
+    if ((fusedOk_ || sweepOk_) && ldsStep_ > 32 * 1024) {
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsStep_));
       HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_step<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsStep_));
     }
@@ -2362,6 +2474,7 @@ class DevHip {
   }
   void launch_sweep_kernel() {
     if (sweepStream_) hipLaunchKernelGGL(k_sweep_stream, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
+    else if (splitProbs_) hipLaunchKernelGGL(sweepFew_ ? k_sweep_few_sp : k_sweep_sp, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
     else if (sweepFew_) hipLaunchKernelGGL(k_sweep_few, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
     else hipLaunchKernelGGL(k_sweep, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
     ++launches_;
@@ -2398,7 +2511,7 @@ class DevHip {
                                );
     }
     ++sweepHandOvers_;
-    if (st == 0) { sweep_fused_one(); return false; }
+    if (st == 0) { if (splitProbs_) sweep_two_one(); else sweep_fused_one(); return false; }
     for (int t = st; t <= T_; ++t) { launch_step(t); ++launches_; }
     if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_));
     return false;
@@ -2407,7 +2520,7 @@ class DevHip {
   // (s4b_set_device_sharing) the two-kernel tree update: the fused launch keeps every compute unit busy with one workgroup of 8 register-heavy
   // waves and leaves no room for the other chains' kernels (measured at n = 1e6, 4 chains: 512 against 425 iterations/s in aggregate) — the same
   // rule choose_path applies where the persistent sweep does not exist.  Both start from and leave the state every path shares between sweeps.
-  void sweep_fused_or_two_one() { if (sharing_ >= 3) sweep_two_one(); else sweep_fused_one(); }
+  void sweep_fused_or_two_one() { if (sharing_ >= 3 || splitProbs_) sweep_two_one(); else sweep_fused_one(); }
   void sweep_two_one() {
     hipLaunchKernelGGL(k_control, dim3(1), dim3(CBLOCK), 0, stream_, a_, -1, 0); ++launches_;
     for (int t = 0; t < T_; ++t) {
@@ -2675,7 +2788,7 @@ class DevHip {
       if (st < 0 || st > T_ + 1) throw std::runtime_error("persistent tree sweep: the launch did not complete");
       if (st != T_ + 1) {
         ++sweepHandOvers_;
-        if (st == 0) sweep_fused_one();
+        if (st == 0) { if (splitProbs_) sweep_two_one(); else sweep_fused_one(); }
         else { for (int t = st; t <= T_; ++t) { launch_step(t); ++launches_; }
                if (((T_ + 1) & 1) == 1) HIP_OK(hipMemcpyAsync(a_.rngF, a_.rngF + 1, sizeof(MTState), hipMemcpyDeviceToDevice, stream_)); }
       }
@@ -3094,7 +3207,7 @@ class DevHip {
   int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1; bool binary_ = false;
   size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0; bool useFused_ = false, fusedAuto_ = false, fusedOk_ = false;
   enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_SWEEP = 4, PATH_STREAM = 5 };
-  bool sweepOk_ = false, sweepRegsOk_ = false, sweepStreamOk_ = false, sweepSolo_ = false, sweepFew_ = false, sweepStream_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
+  bool splitProbs_ = false; bool sweepOk_ = false, sweepRegsOk_ = false, sweepStreamOk_ = false, sweepSolo_ = false, sweepFew_ = false, sweepStream_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
   int64_t sweepCount_ = 0, sweepHandOvers_ = 0;
   int64_t sweepLaunchesRun_ = 0, sweepTreesInside_ = 0, sweepSpecSteps_ = 0, sweepSpecOk_ = 0;
   int xbufParity_ = 0; long long dbgSweepNo_ = 0; int sweepGrid_ = 0;

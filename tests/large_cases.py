@@ -4,9 +4,10 @@ tests/test_gpu_large.py (eight of them in the driver-run suite, VERDICT r05 item
 import numpy as np
 
 
-def large_case(seed, n=None, iters=None, deep=None, k_chi=None, trees=None):
+def large_case(seed, n=None, iters=None, deep=None, k_chi=None, trees=None, split_probs=False):
     """`n`, `iters` (warm-up, total), `deep` (True: trees of tens of leaves from the prior, i.e. hand-overs to k_step), `k_chi` ((df, scale) of a
-    modeled k) and `trees` override what the seed drew; everything else stays the seed's."""
+    modeled k) and `trees` override what the seed drew; everything else stays the seed's.  `split_probs`: cgm(split.probs = ) with weights drawn from a
+    generator of their own (the seed's other draws stay what they are) — the persistent sweep then runs as k_sweep_sp / k_sweep_few_sp."""
     from stan4bart_amd import GroupTerm, make_sampler_args
     g = np.random.default_rng(500000 + seed)
     n0 = int(g.choice([g.integers(50000, 200000), g.integers(200000, 700000), g.integers(700000, 1044000)]))
@@ -36,9 +37,11 @@ def large_case(seed, n=None, iters=None, deep=None, k_chi=None, trees=None):
         bart_args["n.trees"] = int(trees)
     if k_chi is not None:
         bart_args["k"] = ("chi", float(k_chi[0]), float(k_chi[1]))
+    if split_probs:
+        bart_args["split.probs"] = [float(w) for w in np.random.default_rng(900000 + seed).choice([0.05, 0.5, 1.0, 1.0, 3.0, 8.0], size=p)]
     groups = [GroupTerm(g.integers(1, 6, size=n), None, "g.1")] if g.random() < 0.4 else []
     args = make_sampler_args(y, xb, X=x4[:, None], groups=groups, family="binomial" if binary else "gaussian", iter=it, warmup=warmup, bart_args=bart_args,
                              x_test=xb[:50].copy() if g.random() < 0.3 else None)
     if bart_args.get("power") == 0.3:
         args.node_capacity = 1024
-    return args, dict(n=n, p=p, binary=binary, **bart_args)
+    return args, dict(n=n, p=p, binary=binary, **{k: v for k, v in bart_args.items() if k != "split.probs"}, split_probs=bool(split_probs))

@@ -73,6 +73,30 @@ def test_busy_fallback_honours_the_sharing_hint(oracle_lib, hip_lib):
     _check(a, b, 1)
 
 
+def test_busy_launches_with_split_probs(oracle_lib, hip_lib):
+    """cgm(split.probs = ): the persistent sweep is k_sweep_sp; a refused launch and its back-off run on the two-kernel update (k_control's
+    pointer-storage control code knows the weights, k_step's wave-register code does not)"""
+    args, _ = friedman_case(n=N, T=9, warmup=6, iter=14, bart_args={"split.probs": {0: 4.0, 3: 0.25, 7: 2.0}})
+    a = run_chain(oracle_lib, "orc_", args)
+    b = run_chain(hip_lib, "s4b_", args, test_hook=(1, 2))
+    _check(a, b, 1)
+
+
+def test_handed_over_sweeps_with_split_probs(oracle_lib, hip_lib):
+    """a deep prior with cgm(split.probs = ): trees outgrow the 64 node slots of the wave-register control code, k_sweep_sp ends early and the sweep is
+    finished with k_step launches — whose control steps then all run in the launch's sequential tail"""
+    kw = dict(n=N, T=3, warmup=5, iter=12, ranef=True, bart_args={"base": 0.99, "power": 0.25, "k": 0.3, "split.probs": [3, 1, 1, 0.5, 1, 2, 1, 1, 0.1]})
+    args, _ = friedman_case(**kw)
+    args.node_capacity = 1024
+    a = run_chain(oracle_lib, "orc_", args)
+    assert a["trace"][:, 4].max() > 32
+    b = run_chain(hip_lib, "s4b_", args, tree_path="persistent")
+    assert b["tree_path"][1] == "persistent"
+    sweeps, handed_over = b["sweep_stats"]
+    assert sweeps == 13 and handed_over > 0, b["sweep_stats"]
+    assert_chain_parity(a, b)
+
+
 def test_the_hook_is_refused_for_anything_else(hip_lib):
     from conftest import make_sampler
     args, _ = friedman_case(n=200)

@@ -3,6 +3,8 @@ published before the verdict and redone when it says otherwise — against the o
 round 6 only tools/fuzz_large.py and tools/soak.py, which the driver never runs, went there; the suite's other fuzz generator stops at
 n = 40 000 = 10 pass workgroups).  Eight configurations of tests/large_cases.py, BART block, 30 and more iterations each: n = 5e4 ... 1.044e6
 (the largest n the persistent sweep takes), two with trees of tens of leaves (sweeps handed over to k_step part-way), two with a modeled k.
+Four more with cgm(split.probs = ): the weighted predictor choice compiled into the wave-register control code (k_sweep_sp / k_sweep_few_sp), one of
+them with a deep prior (the sweeps end as k_step launches whose control steps all run in the launch's tail, the only code of k_step that knows the weights).
 Same bar as everywhere: tree-move trace, trees, generator state bit-exact; floating-point state to 1e-6."""
 import pytest
 
@@ -24,9 +26,18 @@ LARGE = [
 ]
 
 
-@pytest.mark.parametrize("seed,n,iters,deep,k_chi,trees", LARGE)
-def test_large_configuration_on_the_persistent_path(oracle_lib, hip_lib, seed, n, iters, deep, k_chi, trees):
-    args, what = large_case(seed, n=n, iters=iters, deep=deep, k_chi=k_chi, trees=trees)
+# the same with cgm(split.probs = )
+LARGE_SP = [
+    (10, 60_000, (10, 40), False, None, 9),
+    (11, 300_000, (8, 38), False, (1.25, float("inf")), 7),
+    (12, 500_000, (6, 30), True, None, 4),
+    (13, 1_000_000, (10, 40), False, None, 6),
+]
+
+
+@pytest.mark.parametrize("seed,n,iters,deep,k_chi,trees,split_probs", [c + (False,) for c in LARGE] + [c + (True,) for c in LARGE_SP])
+def test_large_configuration_on_the_persistent_path(oracle_lib, hip_lib, seed, n, iters, deep, k_chi, trees, split_probs):
+    args, what = large_case(seed, n=n, iters=iters, deep=deep, k_chi=k_chi, trees=trees, split_probs=split_probs)
     a = run_chain(oracle_lib, "orc_", args, results_type=1)
     b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path="persistent")
     assert b["tree_path"] == ("persistent", "persistent"), (what, b["tree_path"])

@@ -370,6 +370,9 @@ def test_response_scale_extremes(oracle_lib, hip_lib, scale, hmc_mode):
 def _bart_args_cases():
     from test_bart_args import bart_args_cases
     big = [("split_probs_n20000", dict(n=20000, ranef=False, warmup=8, iter=20, bart_args={"split.probs": {0: 3.0, 4: 0.3}, "n.trees": 20})),
+           # (150 predictors: the wave-register code answers for them in three groups of 64 lanes — counts in registers, in registers, in memory)
+           ("split_probs_p150", dict(n=3000, p=150, ranef=False, warmup=8, iter=30, bart_args={"split.probs": {0: 6.0, 3: 4.0, 70: 5.0, 130: 7.0, 148: 0.1}, "n.trees": 10, "n.cuts": 3})),
+           ("split_probs_p150_deep", dict(n=6000, p=150, ranef=False, warmup=8, iter=30, bart_args={"split.probs": {1: 6.0, 64: 9.0, 127: 5.0, 128: 7.0}, "n.trees": 6, "n.cuts": 2, "base": 0.99, "power": 0.6})),
            ("quantile_cuts_n20000", dict(n=20000, ranef=False, warmup=8, iter=20, bart_args={"useQuantiles": True, "n.cuts": 64, "n.trees": 20}))]
     return bart_args_cases() + big
 
@@ -377,8 +380,9 @@ def _bart_args_cases():
 @pytest.mark.parametrize("path", ["persistent", "fused", "two-kernel"])
 @pytest.mark.parametrize("name,kw", _bart_args_cases(), ids=[c[0] for c in _bart_args_cases()])
 def test_split_probs_and_quantile_cuts(oracle_lib, hip_lib, name, kw, path):
-    """cgm(split.probs = ) (reference tests/testthat/test-09-bartArgs.R:20) and dbartsControl(useQuantiles = ) on every tree path:
-    weighted predictor draws run on the pointer-storage control code of the two-kernel path (k_control), whatever path was asked for —
+    """cgm(split.probs = ) (reference tests/testthat/test-09-bartArgs.R:20) and dbartsControl(useQuantiles = ) on every tree path.
+    The weighted predictor draw exists in the persistent sweep (k_sweep_sp / k_sweep_few_sp: the wave-register control code compiled with it)
+    and in the pointer-storage control code of the two-kernel path (k_control), which also serves a request for the fused path —
     s4b_get_tree_path reports both."""
     args, _ = friedman_case(**kw)
     joint = kw["n"] <= 1000
@@ -386,7 +390,10 @@ def test_split_probs_and_quantile_cuts(oracle_lib, hip_lib, name, kw, path):
     b = run_chain(hip_lib, "s4b_", args, results_type=0 if joint else 1, tree_path=path)
     assert b["tree_path"][0] == path
     assert_chain_parity(a, b, stan=joint)
-    assert b["tree_path"][1] == ("two-kernel" if "split.probs" in kw["bart_args"] else path)
+    assert b["tree_path"][1] == ("two-kernel" if "split.probs" in kw["bart_args"] and path != "persistent" else path)
+    if path == "persistent":
+        sweeps, handed_over = b["sweep_stats"]
+        assert sweeps > 0 and handed_over == 0, b["sweep_stats"]
 
 
 @pytest.mark.parametrize("hmc_mode", [0, 1])

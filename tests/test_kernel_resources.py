@@ -30,7 +30,8 @@ def _usage(extra=()):
     assert out.returncode == 0, out.stdout[-2000:]
     blocks = re.split(r"remark: Function Name: ", out.stdout)[1:]
     out = {}
-    for kernel, key in (("7k_sweepE", "k_sweep"), ("14k_sweep_streamE", "k_sweep_stream"), ("11k_sweep_fewE", "k_sweep_few")):      # (mangled names: s4b::k_sweep, ...)
+    for kernel, key in (("7k_sweepE", "k_sweep"), ("14k_sweep_streamE", "k_sweep_stream"), ("11k_sweep_fewE", "k_sweep_few"),
+                        ("10k_sweep_spE", "k_sweep_sp"), ("14k_sweep_few_spE", "k_sweep_few_sp")):      # (mangled names: s4b::k_sweep, ...)
         hit = [b for b in blocks if kernel in b.split()[0]]
         assert len(hit) == 1, [b.split()[0] for b in blocks]
 
@@ -53,3 +54,8 @@ def test_k_sweep_register_allocation_is_the_one_that_was_measured():
     # the launch for few observations per thread (same body, statistics with the missing quads left out)
     w = both["k_sweep_few"]
     assert w["vgprs"] <= 256 and w["occupancy"] >= 2 and w["spill"] <= MAX_SPILLED_VGPRS and w["scratch"] <= MAX_SCRATCH_BYTES, w
+    # cgm(split.probs): the same two launches with the weighted predictor choice in the wave-register control code (+ 2 KiB of LDS: the table of the weights)
+    for key in ("k_sweep_sp", "k_sweep_few_sp"):
+        z = both[key]
+        assert z["vgprs"] <= 256 and z["occupancy"] >= 2 and z["spill"] <= MAX_SPILLED_VGPRS and z["scratch"] <= MAX_SCRATCH_BYTES, (key, z)
+        assert z["lds"] <= u["lds"] + 2072, (key, z, u)
