@@ -1963,6 +1963,51 @@ __global__ __launch_bounds__(BLOCK) void k_test_fits(BartArrays a, double* out) 
   }
 }
 
+// The same for FEW test rows (BASELINE config 4: 747 counterfactual rows, 75 trees — three workgroups of k_test_fits walking 75 trees one after the other,
+// 91 us of dependent loads per iteration): one thread per (row, tree), TF_ROWS rows per workgroup, a wave per row; the leaf values of a row meet in LDS
+// and ONE lane adds them in the order of the trees — the sum k_test_fits forms, bit for bit.
+constexpr int TF_ROWS = BLOCK / 64;
+__global__ __launch_bounds__(BLOCK) void k_test_fits_few(BartArrays a, double* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tfSmem[];
+  double* vals = (double*)tfSmem;      // [TF_ROWS][T]
+  const ScaleState sc = *a.scale;
+  const int lane = threadIdx.x & 63, rw = threadIdx.x >> 6;
+  for (int64_t i0 = (int64_t)blockIdx.x * TF_ROWS; i0 < a.nTest; i0 += (int64_t)gridDim.x * TF_ROWS) {
+    const int64_t i = i0 + rw;
+    if (i < a.nTest) {
+      for (int t = lane; t < a.T; t += 64) {
+        const size_t o = (size_t)t * a.nc;
+        int nd = 0, v = a.var[o];
+        while (v >= 0) {
+          const unsigned x = a.xbinTest[(size_t)v * a.nTestPad + (size_t)i];
+          nd = (x <= (unsigned)a.cut[o + nd]) ? a.left[o + nd] : a.right[o + nd];
+          v = a.var[o + nd];
+        }
+        vals[(size_t)rw * a.T + t] = a.mu[o + nd];
+      }
+    }
+    __syncthreads();
+    if (lane == 0 && i < a.nTest) {
+      double f = 0.0;
+      for (int t = 0; t < a.T; ++t) f += vals[(size_t)rw * a.T + t];
+      out[i] = a.binary ? f : (f + 0.5) * sc.range + sc.min;
+    }
+    __syncthreads();
+  }
+}
+
+// how often every predictor is used by a rule of the current trees (the reference's `varcount`, one row per kept draw): a thread per tree walks it from the
+// root, as the host did on a download of all eight tree arrays per kept iteration.  One workgroup; integer adds: any order.
+__global__ __launch_bounds__(BLOCK) void k_var_counts(BartArrays a, int32_t* out) {
+  for (int j = threadIdx.x; j < a.P; j += BLOCK) out[j] = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < a.T; t += BLOCK) {
+    const TreeView tv = tree_view(a, t);
+    int nd, k; Walker<TreeView> w(tv, 0);
+    while (w.next(nd, k)) if (k == 1) atomicAdd(out + (int)tv.var.get(nd), 1);
+  }
+}
+
 // stored-tree prediction (stan4bart_predictBART): one thread per (test row, kept draw)
 __global__ __launch_bounds__(BLOCK) void k_predict(const uint16_t* xb, int64_t nT, const PackedNode* nodes, const int64_t* treeStart, int64_t S, int T,
                                                    const double* scale, int binary, double* out) {
@@ -2038,6 +2083,8 @@ class DevHip {
     if (sweepStatus_) (void)hipHostFree(sweepStatus_);
     for (void* p : allocs_) (void)hipFree(p);
     if (pinned_) (void)hipHostFree(pinned_);
+    if (testPinned_) (void)hipHostFree(testPinned_);
+    if (varPinned_) (void)hipHostFree(varPinned_);
     if (pinnedAcc_) (void)hipHostFree(pinnedAcc_);
     if (kOut_) (void)hipHostFree(kOut_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -2279,7 +2326,8 @@ class DevHip {
         }
       }
     }
-    if (nTest_) testOut_ = zalloc<double>((size_t)nTest_);
+    varDev_ = zalloc<int32_t>((size_t)P_); HIP_OK(hipHostMalloc(&varPinned_, (size_t)P_ * 4, hipHostMallocDefault));
+    if (nTest_) { testOut_ = zalloc<double>((size_t)nTest_); if (nTest_ <= (int64_t)1 << 22) HIP_OK(hipHostMalloc(&testPinned_, (size_t)nTest_ * 8, hipHostMallocDefault)); }
     // ---- launch configuration
     gridN_ = a.grid;   // one launch geometry for every O(N) kernel: the partial buffers are sized by it
 #ifdef S4B_CONTROL_TIMING
@@ -2942,9 +2990,44 @@ class DevHip {
       fprintf(stderr, "DBG k_tree per-WG us: stage %.2f pass %.2f (n=%lld)\n", h[8]/100.0/h[10], h[9]/100.0/h[10], h[10]);       fprintf(stderr, "DBG control per-call us: stage %.2f (loads %.2f wait-reduce %.2f) decide %.2f own-propose %.2f out %.2f n=%lld | candidate hit %lld, winner propose-done at %.2f, end at %.2f\n", h[0]/100.0/h[4], h[5]/100.0/h[4], h[6]/100.0/h[4], h[1]/100.0/h[4], h[2]/100.0/h[4], h[3]/100.0/h[4], h[4], h[7], h[7] ? h[14]/100.0/h[7] : 0.0, h[7] ? h[15]/100.0/h[7] : 0.0); }
 #endif
   }
+  void launch_test_fits() {
+    const size_t lds = (size_t)TF_ROWS * (size_t)T_ * 8;
+    if (nTest_ <= 65536 && lds <= 48 * 1024) {      // few rows: a thread per (row, tree)
+      const int g = (int)std::min<int64_t>(GRID_MAX, std::max<int64_t>(1, (nTest_ + TF_ROWS - 1) / TF_ROWS));
+      hipLaunchKernelGGL(k_test_fits_few, dim3(g), dim3(BLOCK), lds, stream_, a_, testOut_);
+    } else {
+      const int g = (int)std::min<int64_t>(GRID_MAX, std::max<int64_t>(1, (nTest_ + BLOCK - 1) / BLOCK));
+      hipLaunchKernelGGL(k_test_fits, dim3(g), dim3(BLOCK), 0, stream_, a_, testOut_);
+    }
+    ++launches_;
+  }
+  // The fits of the test rows of an iteration only need the trees of its sweep: run() asks for them BEFORE the sweep (request_test_fits), stan_inputs() queues
+  // the kernel and the copy to pinned host memory behind the Stan block's input kernels — in front of its wait for their result — and test_fits() finds them
+  // done: no launch + wait of their own per iteration.  A sweep that was handed over forms the Stan inputs again, and these with them.
+  void request_test_fits() { testWanted_ = nTest_ > 0 && testPinned_ != nullptr; testQueued_ = false; }
+  void request_var_counts() { varWanted_ = true; varQueued_ = false; }      // (the same for the predictors' use counts)
+  void queue_test_fits_if_wanted() {
+    if (testWanted_) {
+      launch_test_fits();
+      HIP_OK(hipMemcpyAsync(testPinned_, testOut_, (size_t)nTest_ * 8, hipMemcpyDeviceToHost, stream_));
+      testQueued_ = true;
+    }
+    if (varWanted_) { launch_var_counts(); varQueued_ = true; }
+  }
+  void launch_var_counts() {
+    hipLaunchKernelGGL(k_var_counts, dim3(1), dim3(BLOCK), 0, stream_, a_, varDev_); ++launches_;
+    HIP_OK(hipMemcpyAsync(varPinned_, varDev_, (size_t)P_ * 4, hipMemcpyDeviceToHost, stream_));
+  }
+  void var_counts(int32_t* out) {
+    if (!(varWanted_ && varQueued_)) launch_var_counts();
+    varWanted_ = false; varQueued_ = false;
+    sync();
+    std::memcpy(out, varPinned_, (size_t)P_ * 4);
+  }
   void test_fits(double* out) {
-    int g = (int)std::min<int64_t>(GRID_MAX, std::max<int64_t>(1, (nTest_ + BLOCK - 1) / BLOCK));
-    hipLaunchKernelGGL(k_test_fits, dim3(g), dim3(BLOCK), 0, stream_, a_, testOut_); ++launches_;
+    if (testWanted_ && testQueued_) { sync(); std::memcpy(out, testPinned_, (size_t)nTest_ * 8); testWanted_ = false; testQueued_ = false; return; }
+    testWanted_ = false; testQueued_ = false;
+    launch_test_fits();
     download(out, testOut_, (size_t)nTest_); sync();
   }
 
@@ -2969,6 +3052,7 @@ class DevHip {
     flush_hand_off();
     if (stanFused_) {
       launch_stan_fused(mode, wantTrain ? 1 : 0, false);
+      queue_test_fits_if_wanted();
       if (!fetch_fused(cX, cZ, s0)) { reduce_pipeline(mode, wantTrain ? 1 : 0, 0); fetch_out(cX, cZ, s0); recentre_scales(cX, cZ, *s0); }
     } else { reduce_pipeline(mode, wantTrain ? 1 : 0, 0); fetch_out(cX, cZ, s0); }
     if (wantTrain && trainOut) { download(trainOut, s_.train, (size_t)n_); sync(); }
@@ -3218,7 +3302,8 @@ class DevHip {
   BartArrays a_; StanArrays s_;
   std::vector<void*> allocs_;
   char* arena_ = nullptr; size_t arenaSize_ = 0, arenaUsed_ = 0;
-  double* pinned_ = nullptr; double* testOut_ = nullptr; double* latX_ = nullptr;
+  double* pinned_ = nullptr; double* testOut_ = nullptr; double* latX_ = nullptr; double* testPinned_ = nullptr; bool testWanted_ = false, testQueued_ = false;
+  int32_t* varDev_ = nullptr; int32_t* varPinned_ = nullptr; bool varWanted_ = false, varQueued_ = false;
   unsigned long long* fusedAcc_ = nullptr; int32_t* fusedBad_ = nullptr; unsigned long long* pinnedAcc_ = nullptr;
   size_t fusedLds_ = 0; int fusedParity_ = 0; bool stanFused_ = false;
   uint32_t fusedSeq_ = 0; int zFixed_ = -1; const double* inlineBeta_ = nullptr; const double* inlineB_ = nullptr;

@@ -307,6 +307,8 @@ class SamplerCore {
       if (doBart) {
         treeUpdates_ += (long)T_ * thin_;
         const bool emit = !lastOnly || iter == numIter - 1;
+        if (nTest_ && emit && ((out && out->bart_test) || callback_)) dev_.request_test_fits();
+        if (out && emit && out->bart_varcount) dev_.request_var_counts();
         dev_.sweep_and_stan_inputs(thin_, stan_mode(), wantTrain && emit, cX_.data(), cZ_.data(), &s0_, (wantTrain && emit) ? train.data() : nullptr);
         if (timing) { tph[2] += now() - t0; t0 = now(); }
         if (nTest_ && emit && ((out && out->bart_test) || callback_)) dev_.test_fits(test.data());
@@ -315,7 +317,7 @@ class SamplerCore {
           if (out->bart_k) out->bart_k[slot] = kModeled_ ? dev_.k_current() : kFixed_;
           if (out->bart_train) std::memcpy(out->bart_train + slot * n_, train.data(), n_ * sizeof(double));
           if (out->bart_test && nTest_) std::memcpy(out->bart_test + slot * nTest_, test.data(), nTest_ * sizeof(double));
-          if (out->bart_varcount) var_counts(out->bart_varcount + slot * (size_t)P_);
+          if (out->bart_varcount) dev_.var_counts(out->bart_varcount + slot * (size_t)P_);
         }
         if (keepTrees_ && !isWarmup) keep_current_trees();
         // (a non-zero return stops the run after this iteration: the reference's callback is R code whose error unwinds run(),

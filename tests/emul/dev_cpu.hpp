@@ -260,6 +260,12 @@ class DevCpu {
   void set_test_hook(int, int64_t) { throw std::invalid_argument("set_test_hook: the emulation of the device layer has no persistent launch"); }
   void sweep_spec(int64_t out[4]) const { out[0] = 0; out[1] = 0; out[2] = 0; out[3] = 0; }
   void profile_sweep(int nSweeps, int thin, double* out) { for (int i = 0; i < 8; ++i) out[i] = 0.0; for (int k = 0; k < nSweeps; ++k) sweep(thin); }
+  void request_test_fits() {}      // (the device layer queues them behind the Stan inputs: nothing to overlap here)
+  void request_var_counts() {}
+  void var_counts(int32_t* out) {
+    for (int j = 0; j < P_; ++j) out[j] = 0;
+    for (int t = 0; t < T_; ++t) { TreeView tv = tree_view(a_, t); int nd, k; Walker<TreeView> w(tv, 0); while (w.next(nd, k)) if (k == 1) ++out[tv.var.get(nd)]; }
+  }
   void test_fits(double* out) {
     for (size_t i = 0; i < nTest_; ++i) {
       double f = 0.0;
