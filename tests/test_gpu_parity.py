@@ -396,6 +396,21 @@ def test_split_probs_and_quantile_cuts(oracle_lib, hip_lib, name, kw, path):
         assert sweeps > 0 and handed_over == 0, b["sweep_stats"]
 
 
+def test_test_row_fits_on_both_kernels(oracle_lib, hip_lib):
+    """The fits of the test rows: up to 65 536 rows a thread per (row, tree) (k_test_fits_few), beyond that a thread per row (k_test_fits).  70 000 test rows
+    that ARE the training rows: both against the oracle, and against the training fits of the same draw; the predictors' use counts (formed on the device
+    since round 6) with them."""
+    for n, n_test in ((70_000, 70_000), (70_000, 3_001)):
+        args, _ = friedman_case(n=n, T=9, warmup=3, iter=6, ranef=False, n_test=n_test)
+        a = run_chain(oracle_lib, "orc_", args)
+        b = run_chain(hip_lib, "s4b_", args)
+        assert_chain_parity(a, b)
+        fits = b["sample"]["bart"]
+        assert fits["test"].shape[0] == n_test
+        np.testing.assert_allclose(fits["test"], fits["train"][:n_test], rtol=1e-12, atol=1e-12)
+        assert np.array_equal(a["sample"]["bart"]["varcount"], fits["varcount"])
+
+
 @pytest.mark.parametrize("hmc_mode", [0, 1])
 def test_handed_over_sweeps_in_a_joint_chain(oracle_lib, hip_lib, hmc_mode):
     """The host queues the Stan inputs behind k_sweep without waiting for its status word (sweep_and_stan_inputs); a sweep that ends early —
