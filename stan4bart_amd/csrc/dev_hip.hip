@@ -2241,9 +2241,20 @@ class DevHip {
         // beyond SW_PF quads per pass thread the residual does not fit the registers.  The STREAMING variant of the same launch (k_sweep_stream:
         // the pass waves read and write the residual per tree, 22 B per observation and tree update like k_tree, everything else as k_sweep)
         // exists for every size but is only taken on request (choose_path); its workgroup counts must fit the 21-bit field of the exchange words
-        const bool common = stepOk && d.weights == nullptr && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount && sweep_lds_bytes() + 40 * 1024 <= 160 * 1024;
+        // (observation weights: k_sweep_w keeps the workgroup's 4 096 weights in 32 KiB of LDS beside the tables; not together with split.probs,
+        // not on the streaming variant)
+        weighted_ = d.weights != nullptr;
+        size_t staticLds = 40 * 1024;
+        if (weighted_) { hipFuncAttributes fa; HIP_OK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_sweep_w))); staticLds = fa.sharedSizeBytes + 512; }      // (its static part: tables + 32 KiB of weights)
+        const bool common = stepOk && !(weighted_ && splitProbs_) && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount &&
+                            sweep_lds_bytes() + staticLds <= 160 * 1024;
+        if (weighted_) {      // the power of two that brings the largest weight into (0.5, 1]
+          double mx = 0.0; for (int64_t i = 0; i < n_; ++i) mx = std::max(mx, d.weights[i]);
+          int e = 0; if (mx > 0.0 && std::isfinite(mx)) (void)std::frexp(mx, &e);
+          wScale_ = std::ldexp(1.0, -e); wUnscale_ = std::ldexp(1.0, e);
+        }
         sweepRegsOk_ = common && nQuads <= (int64_t)(a.gridF - 1) * SW_PT * SW_PF;
-        sweepStreamOk_ = common && !splitProbs_ && (n_ + a.gridF - 2) / (a.gridF - 1) + 4 * SW_PT < (int64_t)1 << 21;
+        sweepStreamOk_ = common && !splitProbs_ && !weighted_ && (n_ + a.gridF - 2) / (a.gridF - 1) + 4 * SW_PT < (int64_t)1 << 21;
         sweepOk_ = sweepRegsOk_ || sweepStreamOk_;
         // at most 4096 observations: ONE workgroup holds them all and does the control duties too (no exchange: dev_sweep.inc "solo")
         sweepSolo_ = nQuads <= (int64_t)SW_PT * SW_PF;
@@ -2262,6 +2273,7 @@ class DevHip {
           HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_few), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
           HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_sp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
           HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_few_sp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
+          HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds_bytes()));
         }
       }
       choose_path();
@@ -2522,6 +2534,7 @@ class DevHip {
   }
   void launch_sweep_kernel() {
     if (sweepStream_) hipLaunchKernelGGL(k_sweep_stream, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
+    else if (weighted_) hipLaunchKernelGGL(k_sweep_w, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
     else if (splitProbs_) hipLaunchKernelGGL(sweepFew_ ? k_sweep_few_sp : k_sweep_sp, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
     else if (sweepFew_) hipLaunchKernelGGL(k_sweep_few, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
     else hipLaunchKernelGGL(k_sweep, dim3(sweepGrid_), dim3(FBLOCK), sweep_lds_bytes(), stream_, a_, sweep_args());
@@ -2532,7 +2545,7 @@ class DevHip {
     unsigned long long* cur = xbuf_ + (size_t)xbufParity_ * (XC_RING_WORDS + XC_ROLL_WORDS);
     unsigned long long* nxt = xbuf_ + (size_t)(1 - xbufParity_) * (XC_RING_WORDS + XC_ROLL_WORDS);
     xbufParity_ ^= 1;
-    return SweepArgs{cur, sweepStatusDev_, nxt};
+    return SweepArgs{cur, sweepStatusDev_, nxt, wScale_, wUnscale_};
   }
   // the launch has ended (the caller waited for it or for something behind it on the stream): true = the sweep is complete, false = the
   // rest of it (or all of it) has just been queued as k_step launches
@@ -3291,7 +3304,7 @@ class DevHip {
   int64_t n_ = 0, nTest_ = 0; int P_ = 0, T_ = 0, nc_ = 0, K_ = 0, q_ = 0, gridN_ = 1; bool binary_ = false;
   size_t ldsApply_ = 0, ldsControl_ = 0, ldsTree_ = 0, ldsStep_ = 0; bool useFused_ = false, fusedAuto_ = false, fusedOk_ = false;
   enum { PATH_TWO = 1, PATH_FUSED = 2, PATH_SWEEP = 4, PATH_STREAM = 5 };
-  bool splitProbs_ = false; bool sweepOk_ = false, sweepRegsOk_ = false, sweepStreamOk_ = false, sweepSolo_ = false, sweepFew_ = false, sweepStream_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
+  bool splitProbs_ = false, weighted_ = false; double wScale_ = 1.0, wUnscale_ = 1.0; bool sweepOk_ = false, sweepRegsOk_ = false, sweepStreamOk_ = false, sweepSolo_ = false, sweepFew_ = false, sweepStream_ = false; unsigned long long* xbuf_ = nullptr; int32_t* sweepStatus_ = nullptr; int32_t* sweepStatusDev_ = nullptr;
   int64_t sweepCount_ = 0, sweepHandOvers_ = 0;
   int64_t sweepLaunchesRun_ = 0, sweepTreesInside_ = 0, sweepSpecSteps_ = 0, sweepSpecOk_ = 0;
   int xbufParity_ = 0; long long dbgSweepNo_ = 0; int sweepGrid_ = 0;

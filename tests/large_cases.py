@@ -4,10 +4,11 @@ tests/test_gpu_large.py (eight of them in the driver-run suite, VERDICT r05 item
 import numpy as np
 
 
-def large_case(seed, n=None, iters=None, deep=None, k_chi=None, trees=None, split_probs=False):
+def large_case(seed, n=None, iters=None, deep=None, k_chi=None, trees=None, split_probs=False, weights=False):
     """`n`, `iters` (warm-up, total), `deep` (True: trees of tens of leaves from the prior, i.e. hand-overs to k_step), `k_chi` ((df, scale) of a
     modeled k) and `trees` override what the seed drew; everything else stays the seed's.  `split_probs`: cgm(split.probs = ) with weights drawn from a
-    generator of their own (the seed's other draws stay what they are) — the persistent sweep then runs as k_sweep_sp / k_sweep_few_sp."""
+    generator of their own (the seed's other draws stay what they are) — the persistent sweep then runs as k_sweep_sp / k_sweep_few_sp.  `weights`: observation weights from a generator of their own, a
+    scale between 1e-3 and 1 and a few weights a thousand times smaller than the rest (k_sweep_w); not for binary responses, not together with split_probs."""
     from stan4bart_amd import GroupTerm, make_sampler_args
     g = np.random.default_rng(500000 + seed)
     n0 = int(g.choice([g.integers(50000, 200000), g.integers(200000, 700000), g.integers(700000, 1044000)]))
@@ -40,8 +41,17 @@ def large_case(seed, n=None, iters=None, deep=None, k_chi=None, trees=None, spli
     if split_probs:
         bart_args["split.probs"] = [float(w) for w in np.random.default_rng(900000 + seed).choice([0.05, 0.5, 1.0, 1.0, 3.0, 8.0], size=p)]
     groups = [GroupTerm(g.integers(1, 6, size=n), None, "g.1")] if g.random() < 0.4 else []
-    args = make_sampler_args(y, xb, X=x4[:, None], groups=groups, family="binomial" if binary else "gaussian", iter=it, warmup=warmup, bart_args=bart_args,
+    w = None
+    if weights and not binary and not split_probs:
+        gw = np.random.default_rng(700000 + seed)
+        # (weights of O(1) and below.  A weight multiplies an observation's precision; the reference — dbarts, restated in oracle/bart_ref.hpp — gives a branch with an
+        # EMPTY leaf the log-likelihood -1e7 and compares it with the FULL integrated likelihood of the other branch, within-leaf sum of squares included, while the
+        # device code carries the terms that do not cancel between two non-empty branches only: once sum of w d^2 / sigma^2 of a branch exceeds 2e7 — weights of 40 at
+        # n = 4e5 — the reference ACCEPTS a rule that leaves a leaf empty and the device code rejects it: seed 79 of the first version of this generator)
+        w = gw.uniform(0.25, 4.0, n) * float(gw.choice([1e-3, 0.03, 0.125, 1.0, 1.0]))
+        w[gw.integers(0, n, 100)] *= 1e-3
+    args = make_sampler_args(y, xb, X=x4[:, None], groups=groups, family="binomial" if binary else "gaussian", iter=it, warmup=warmup, bart_args=bart_args, weights=w,
                              x_test=xb[:50].copy() if g.random() < 0.3 else None)
     if bart_args.get("power") == 0.3:
         args.node_capacity = 1024
-    return args, dict(n=n, p=p, binary=binary, **{k: v for k, v in bart_args.items() if k != "split.probs"}, split_probs=bool(split_probs))
+    return args, dict(n=n, p=p, binary=binary, **{k: v for k, v in bart_args.items() if k != "split.probs"}, split_probs=bool(split_probs), weights=w is not None)

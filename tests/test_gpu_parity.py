@@ -67,11 +67,13 @@ def test_fused_path_joint_chain(oracle_lib, hip_lib, kw):
 
 
 def test_automatic_path_is_the_persistent_sweep(hip_lib):
-    """no weights, at most 16 observations per pass thread: k_sweep — also when chains share the device (round 5: they take turns);
-    with weights: the fused launch, and two kernels per tree when three chains share the device"""
+    """at most 16 observations per pass thread: the persistent sweep — k_sweep, with observation weights k_sweep_w (round 6) — also when chains share the
+    device (round 5: they take turns); weights together with split.probs: two kernels per tree"""
     from conftest import make_sampler
     w = np.random.default_rng(1).random(3000) + 0.5
-    for kw, sharing, want in ((dict(), None, "persistent"), (dict(weights=w), None, "fused"), (dict(), 3, "persistent"), (dict(weights=w), 3, "two-kernel")):
+    sp = {"split.probs": {0: 2.0}}
+    for kw, sharing, want in ((dict(), None, "persistent"), (dict(weights=w), None, "persistent"), (dict(), 3, "persistent"), (dict(weights=w), 3, "persistent"),
+                              (dict(bart_args=sp), None, "persistent"), (dict(weights=w, bart_args=sp), None, "two-kernel")):
         args, _ = friedman_case(n=3000, T=5, warmup=2, iter=4, **kw)
         s = make_sampler(hip_lib, "s4b_", args)
         try:
@@ -245,12 +247,14 @@ def test_trees_with_more_than_128_node_slots(oracle_lib, hip_lib):
 
 @pytest.mark.parametrize("sharing", [(4, None), (None, 4), (4, 1)])
 def test_device_sharing_hint_switches_the_tree_update_without_changing_the_draws(oracle_lib, hip_lib, sharing):
-    """s4b_set_device_sharing (where the persistent sweep does not apply — here: observation weights): three or more chains per GPU ->
-    two-kernel tree update, fewer -> the fused launch; given before the warm-up, between warm-up and sampling, and back again — the
+    """s4b_set_device_sharing (where the persistent sweep does not apply — here: more than 16 observations per pass thread, n = 1.1e6): three or more
+    chains per GPU -> two-kernel tree update, fewer -> the fused launch; given before the warm-up, between warm-up and sampling, and back again — the
     chain is the oracle's either way."""
-    args, _ = friedman_case(n=3000, T=12, warmup=8, iter=16, ranef=True, weights=np.random.default_rng(7).random(3000) + 0.5)
+    n = 1_100_000
+    args, _ = friedman_case(n=n, T=3, warmup=3, iter=6, ranef=True, weights=np.random.default_rng(7).random(n) + 0.5)
     a = run_chain(oracle_lib, "orc_", args)
     b = run_chain(hip_lib, "s4b_", args, sharing=sharing)
+    assert b["tree_path"][1] in ("fused", "two-kernel")
     assert_chain_parity(a, b)
 
 
@@ -301,10 +305,40 @@ def test_observation_weights(oracle_lib, hip_lib, kw):
     w = np.random.default_rng(5).uniform(0.3, 3.0, n)
     a = run_chain(oracle_lib, "orc_", friedman_case(weights=w, **kw_o)[0])
     b = run_chain(hip_lib, "s4b_", friedman_case(weights=w, **kw)[0])
+    assert b["tree_path"][1] == "persistent"          # (k_sweep_w, round 6; one workgroup at these sizes — the full grid: test_observation_weights_on_the_full_grid)
     assert_chain_parity(a, b)
+    for path in ("fused", "two-kernel"):
+        e = run_chain(hip_lib, "s4b_", friedman_case(weights=w, **kw)[0], tree_path=path)
+        assert e["tree_path"][1] == path
+        assert_chain_parity(a, e)
     c = run_chain(hip_lib, "s4b_", friedman_case(**kw)[0])
     d = run_chain(hip_lib, "s4b_", friedman_case(weights=np.ones(n), **kw)[0])
     np.testing.assert_array_equal(d["trace"], c["trace"])          # unit weights == no weights
+
+
+@pytest.mark.parametrize("n,T,scale,deep", [(24_000, 9, 1.0, False), (100_000, 7, 1e6, False), (300_000, 5, 1e-7, False), (60_000, 3, 3.0, True), (1_000_000, 6, 1.0, False)])
+def test_observation_weights_on_the_full_grid(oracle_lib, hip_lib, n, T, scale, deep):
+    """k_sweep_w with 6 ... 255 pass workgroups exchanging (sum of w r, count, sum of w) per bin — the sums of the weights travel as bins of their own, everything
+    times a power of two that brings the largest weight into (0.5, 1] —; weights of 1e6 and 1e-7 (the fixed-point words hold sums of O(1) terms whatever the
+    user's scale), a few weights 1e-3 of the rest; a deep prior (sweeps end as k_step<weighted> launches; trees beyond 32 bins end the launch: 2 x 32 "bins")."""
+    g = np.random.default_rng(n)
+    w = g.uniform(0.3, 3.0, n) * scale
+    w[g.integers(0, n, 50)] *= 1e-3
+    kw = dict(n=n, T=T, warmup=6, iter=14, ranef=False)
+    if deep:
+        kw["bart_args"] = {"base": 0.99, "power": 0.3, "k": 0.3}
+    args, _ = friedman_case(weights=w, **kw)
+    if deep:
+        args.node_capacity = 1024
+    a = run_chain(oracle_lib, "orc_", args, results_type=1)
+    b = run_chain(hip_lib, "s4b_", args, results_type=1, tree_path="persistent")
+    assert b["tree_path"] == ("persistent", "persistent")
+    assert_chain_parity(a, b, stan=False)
+    sweeps, handed = b["sweep_stats"]
+    assert sweeps == 15 and (handed > 0) == deep, b["sweep_stats"]
+    if not deep:
+        launches, inside, early, ok = b["sweep_spec"]
+        assert inside == sweeps * T and early > 0.3 * inside, b["sweep_spec"]
 
 
 @pytest.mark.parametrize("P", [100, 140])

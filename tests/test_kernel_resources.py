@@ -31,7 +31,7 @@ def _usage(extra=()):
     blocks = re.split(r"remark: Function Name: ", out.stdout)[1:]
     out = {}
     for kernel, key in (("7k_sweepE", "k_sweep"), ("14k_sweep_streamE", "k_sweep_stream"), ("11k_sweep_fewE", "k_sweep_few"),
-                        ("10k_sweep_spE", "k_sweep_sp"), ("14k_sweep_few_spE", "k_sweep_few_sp")):      # (mangled names: s4b::k_sweep, ...)
+                        ("10k_sweep_spE", "k_sweep_sp"), ("14k_sweep_few_spE", "k_sweep_few_sp"), ("9k_sweep_wE", "k_sweep_w")):      # (mangled names: s4b::k_sweep, ...)
         hit = [b for b in blocks if kernel in b.split()[0]]
         assert len(hit) == 1, [b.split()[0] for b in blocks]
 
@@ -59,3 +59,7 @@ def test_k_sweep_register_allocation_is_the_one_that_was_measured():
         z = both[key]
         assert z["vgprs"] <= 256 and z["occupancy"] >= 2 and z["spill"] <= MAX_SPILLED_VGPRS and z["scratch"] <= MAX_SCRATCH_BYTES, (key, z)
         assert z["lds"] <= u["lds"] + 2072, (key, z, u)
+    # observation weights: the instantiation with the skippable quads (without them: 878 spilled registers), + 32 KiB of LDS for the workgroup's weights
+    y = both["k_sweep_w"]
+    assert y["vgprs"] <= 256 and y["occupancy"] >= 2 and y["spill"] <= MAX_SPILLED_VGPRS and y["scratch"] <= MAX_SCRATCH_BYTES, y
+    assert y["lds"] <= u["lds"] + 32768 + 64, (y, u)

@@ -7,6 +7,7 @@ R=$O/campaign.txt; : > "$R"
 echo "== $TAG campaign on $(hostname), libs4b.so $(sha256sum stan4bart_amd/csrc/libs4b.so | cut -c1-16)" >> "$R"
 timeout 1500 python tools/fuzz_large.py 0 160 persistent 2>&1 | tail -n 1 >> "$R"
 timeout 900 python tools/fuzz_large.py 0 80 persistent sp 2>&1 | tail -n 1 >> "$R"
+timeout 900 python tools/fuzz_large.py 0 80 persistent w 2>&1 | tail -n 1 >> "$R"
 timeout 900 python tools/fuzz_range.py 160 1360 persistent 2>&1 | tail -n 1 >> "$R"
 timeout 600 python tools/fuzz_range.py 160 760 fused 2>&1 | tail -n 1 >> "$R"
 timeout 600 python tools/fuzz_range.py 160 760 two-kernel 2>&1 | tail -n 1 >> "$R"

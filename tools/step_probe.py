@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--iters", type=int, default=6)
     ap.add_argument("--path", default="auto", choices=["auto", "two-kernel", "fused", "persistent", "stream"])
     ap.add_argument("--split-probs", action="store_true", help="cgm(split.probs = ): weights 3 on the first five predictors, 0.2 on the last five, 1 elsewhere")
+    ap.add_argument("--weights", action="store_true", help="observation weights, uniform on (0.3, 3)")
     a = ap.parse_args()
     from stan4bart_amd import RRng, make_sampler_args
     from stan4bart_amd._lib import load_library
@@ -33,7 +34,7 @@ def main():
     x4 = g.random(a.n)
     z = (g.random(a.n) < 0.2).astype(np.float64)
     y = 10 * np.sin(np.pi * xb[:, 0] * xb[:, 1]) + 20 * (xb[:, 2] - 0.5) ** 2 + 5 * xb[:, 3] + 10 * x4 + 5 * z + g.standard_normal(a.n)
-    args = make_sampler_args(y, xb, X=np.column_stack([x4, z]), groups=[], iter=2 * a.iters, warmup=a.iters, keep_fits=False,
+    args = make_sampler_args(y, xb, X=np.column_stack([x4, z]), groups=[], iter=2 * a.iters, warmup=a.iters, keep_fits=False, weights=g.uniform(0.3, 3.0, a.n) if a.weights else None,
                              bart_args=dict({"n.trees": a.trees}, **({"split.probs": [3.0 if j < 5 else (0.2 if j >= a.p - 6 else 1.0) for j in range(a.p - 1)]} if a.split_probs else {})))
     rng = RRng(4321)
     args.seed = int(rng.sample_int(2147483647, 1)[0])
