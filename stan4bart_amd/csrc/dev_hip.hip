@@ -2244,9 +2244,10 @@ class DevHip {
         // (observation weights: k_sweep_w keeps the workgroup's 4 096 weights in 32 KiB of LDS beside the tables; not together with split.probs,
         // not on the streaming variant)
         weighted_ = d.weights != nullptr;
+        constexpr bool weightedSweepBuilt = !S4B_LINEAR && S4B_WAVERED;      // (the build variants with another reduction of the statistics have no k_sweep_w: weighted samplers take the per-tree kernels there)
         size_t staticLds = 40 * 1024;
-        if (weighted_) { hipFuncAttributes fa; HIP_OK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_sweep_w))); staticLds = fa.sharedSizeBytes + 512; }      // (its static part: tables + 32 KiB of weights)
-        const bool common = stepOk && !(weighted_ && splitProbs_) && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount &&
+        if (weighted_ && weightedSweepBuilt) { hipFuncAttributes fa; HIP_OK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_sweep_w))); staticLds = fa.sharedSizeBytes + 512; }      // (its static part: tables + 32 KiB of weights)
+        const bool common = stepOk && !(weighted_ && (splitProbs_ || !weightedSweepBuilt)) && a.gridF >= 2 && a.gridF <= 256 && a.gridF <= prop.multiProcessorCount &&
                             sweep_lds_bytes() + staticLds <= 160 * 1024;
         if (weighted_) {      // the power of two that brings the largest weight into (0.5, 1]
           double mx = 0.0; for (int64_t i = 0; i < n_; ++i) mx = std::max(mx, d.weights[i]);
