@@ -54,7 +54,8 @@ typedef struct {
   const double* split_probs; /* cgm(split.probs = ): NULL (predictors equally likely) or one positive weight per predictor, any scale:
                               * a rule's predictor is drawn with probability weight / sum of the weights of the predictors still
                               * available at the node, and the tree prior carries the same term (R/stan4bart_fit.R:466-475;
-                              * tests/testthat/test-09-bartArgs.R:20).  Tree updates then run on the two-kernel path.           */
+                              * tests/testthat/test-09-bartArgs.R:20).  Tree updates then run on the persistent sweep's k_sweep_sp
+                              * where that applies, else on the two-kernel path.                                                */
   int32_t use_quantiles;     /* dbartsControl(useQuantiles = ) through bart_args (R/stan4bart_fit.R:440-444): 0 uniform cut points
                               * between the column extremes, 1 cut points from the distinct values (n_cuts is then a maximum)    */
   int32_t interface_version; /* must be S4B_INTERFACE_VERSION: create() refuses anything else.  This struct and s4b_results have grown fields over the revisions
@@ -287,7 +288,7 @@ int S4B_FN(get_leaf_assignment)(s4b_sampler* s, int32_t tree, int32_t* out);
  * one fit in parallel workers; here they can be host threads on one GPU).  Where the persistent sweep applies (set_tree_path) the hint
  * changes nothing since round 5: samplers of one process take turns on the device, launches of other processes are sorted out by the
  * roll call at the start of every persistent launch, and the aggregate rate is higher than on the per-tree kernels.
- * Elsewhere — observation weights, cgm(split.probs), n > 1.04e6 — the fused launch keeps every CU busy with one register-heavy workgroup,
+ * Elsewhere — n > 1.04e6, observation weights together with cgm(split.probs) — the fused launch keeps every CU busy with one register-heavy workgroup,
  * which is fastest for a chain that has the device to itself; with three or more chains per device the sampler switches to the
  * two-kernel tree update, which leaves room for the other chains' kernels (higher aggregate rate).  The
  * same chain either way: identical tree moves and generator stream, floating-point values equal up to the summation order of the
@@ -297,8 +298,9 @@ int S4B_FN(set_device_sharing)(s4b_sampler* s, int32_t chains);
  * 2 one fused launch per tree (k_step), 4 persistent (k_sweep: ONE launch per sweep, the residual in the registers of the pass waves, bin
  * partials exchanged through order-free integer atomics), 5 persistent with a streaming pass (k_sweep_stream: the same launch, the pass
  * waves read and write the residual per tree; measured slower than 1 / 2 at every size and never chosen automatically).  The automatic
- * choice is 4 wherever it applies — no observation weights, no cgm(split.probs), at most 16
- * observations per pass thread (n <= 1 044 480 on 256 compute units) —, else 2 up to n ~ 4e6, else 1.  A request the sampler cannot honour
+ * choice is 4 wherever it applies — at most 16 observations per pass thread (n <= 1 044 480 on 256 compute units); observation weights
+ * and cgm(split.probs) have their own instantiations of the launch since round 6 (k_sweep_w, k_sweep_sp), the two together do not —,
+ * else 2 up to n ~ 4e6, else 1 (with split.probs always 1).  A request the sampler cannot honour
  * (more than 255 quads per thread for 2, the conditions above for 4 / 5) falls back to the next path down; get_tree_path reports the path
  * in effect.  The same chain on every path (see set_device_sharing).  May be called at any time between runs.
  * get_tree_path: out[0] = the request, out[1] = the path in effect (1, 2, 4 or 5).  (3 was the lagged launch of an earlier revision:
